@@ -1,0 +1,127 @@
+/*
+ * vq_mi355x.h -- C ABI of the MI355X (gfx950) nearest-codebook library  (libvq_mi355x.so).
+ *
+ * The reference (MisterBourbaki/vector-quantization-by-ml) has NO native layer: its hot path is a
+ * sequence of ATen calls issued from Python.  Each entry point below therefore replaces a run of
+ * reference Python lines (cited per function, paths relative to the reference root) rather than an
+ * existing FFI symbol, and is what a maintainer would bind (ctypes stub in INTEGRATION.md).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) unless stated; the library never allocates or frees
+ *     persistent memory and never synchronises the host: work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = default stream);
+ *   - all floating point is fp32, indices are int64 (reference: codebooks.py:354, general.py:128);
+ *   - strides are in ELEMENTS; rows of x / out may be strided (head-split views need no copy);
+ *   - return value: 0 on success, a negative VQ_E* code for argument errors, or a positive
+ *     hipError_t.  vq_last_error() returns a human-readable string for the calling thread.
+ *   - re-entrant across streams; no global mutable state besides the per-thread error string.
+ */
+#ifndef VQ_MI355X_H
+#define VQ_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQ_METRIC_EUCLID 0 /* similarity = -cdist(x, c)      codebooks.py:128-129 */
+#define VQ_METRIC_DOT 1    /* similarity = einsum(x, c)      codebooks.py:122-123 */
+
+#define VQ_E_BADARG (-1)
+#define VQ_E_UNSUPPORTED (-2)
+#define VQ_E_NODEVICE (-3)
+
+/* flags */
+#define VQ_F_STE 1u          /* out = x + (q - x)  (train-mode straight-through, vector_quantize_pytorch.py:273) */
+#define VQ_F_FORCE_SIMPLE 2u /* use the scalar-FMA fallback kernel instead of the MFMA kernel (cross-check)        */
+#define VQ_F_FORCE_SPLIT 4u  /* force the split-K + packed-key path even when the fused path would be chosen        */
+
+/*
+ * Packed codebook image (the layout the search kernel streams through LDS).  For one codebook of
+ * K codes x D dims:  Kp = roundup(K, 32) rows of (Dp + 4) floats, Dp = padded dim chosen by the library
+ * (32/64/128/256/512); inside each group of 8 dims the even dims come first, then the odd ones, values
+ * pre-scaled by -2 (Euclid) or 1 (dot); float Dp of each row holds |c|^2 (d-ordered fmaf chain).
+ * Returns the number of floats ONE packed codebook occupies (including over-copy slack), 0 on bad args.
+ */
+int64_t vq_packed_floats(int K, int D);
+
+/*
+ * Pack `n_codebooks` natural row-major [K, D] codebooks (consecutive ones `cb_stride` floats apart)
+ * into `packed` (consecutive images vq_packed_floats(K, D) floats apart).
+ * Replaces: the per-call operand preparation inside ATen cdist (cat([-2x,|x|^2,1]) / cat([c,1,|c|^2])),
+ * reached from codebooks.py:386.
+ */
+int vq_pack_codebooks_f32(const float *cb, int n_codebooks, int64_t cb_stride, int K, int D, int metric,
+                          float *packed, void *stream);
+
+typedef struct vq_args {
+    /* problem */
+    int32_t H;      /* independent codebooks searched side by side (heads)  -- grid.y              */
+    int32_t Q;      /* residual stages (1 = plain VectorQuantize)                                  */
+    int64_t M;      /* rows per head                                                               */
+    int32_t K;      /* codes per codebook                                                          */
+    int32_t D;      /* dims                                                                        */
+    int32_t metric; /* VQ_METRIC_*                                                                 */
+    uint32_t flags; /* VQ_F_*                                                                      */
+    /* inputs */
+    const float *x;        /* [H][M][D], element (h, m, d) at x[h*x_hs + m*x_rs + d]               */
+    int64_t x_rs, x_hs;
+    const float *cb;       /* natural codebooks: (h, q, k, d) at cb[h*cb_hs + q*cb_qs + k*D + d]    */
+    int64_t cb_hs, cb_qs;  /* (cb_qs = 0: all stages share one codebook)                           */
+    const float *packed;   /* packed images: codebook (h, q) at packed[h*pk_hs + q*pk_qs]           */
+    int64_t pk_hs, pk_qs;
+    /* outputs (any of out / best / sq_err may be NULL) */
+    float *out;            /* quantized (or straight-through) rows, (h, m, d) at out[h*out_hs + m*out_rs + d];
+                              for Q > 1: ((0 + q_1) + q_2) + ...   residual_vq.py:233                */
+    int64_t out_rs, out_hs;
+    int64_t *idx;          /* (h, m, q) at idx[h*idx_hs + m*idx_rs + q*idx_qs]                      */
+    int64_t idx_rs, idx_hs, idx_qs;
+    float *best;           /* winning sqrt-distance (Euclid) / similarity (dot); same indexing as idx */
+    double *sq_err;        /* [Q] : sum over all heads/rows/dims of (q - x)^2 per stage (overwritten;
+                              fixed summation order -> run-to-run reproducible);
+                              commitment loss = weight * sq_err / (H*M*D)   vector_quantize_pytorch.py:362 */
+    /* scratch */
+    void *workspace;       /* >= vq_workspace_bytes() bytes, 16-byte aligned                        */
+    int64_t workspace_bytes;
+} vq_args;
+
+/* Bytes of scratch vq_quantize_f32 / vq_search_keys_f32 may need for (H, M, Q). */
+int64_t vq_workspace_bytes(int H, int64_t M, int Q);
+
+/*
+ * The hot path: search (+ residual loop) + gather + straight-through + squared-error sums.
+ * Replaces Codebook.forward's search core  codebooks.py:386-397  (similarity -> first argmax -> gather),
+ * VectorQuantize.forward's quantize step   vector_quantize_pytorch.py:261-279,337,361-364  and, for Q > 1,
+ * the ResidualVQ loop                      residual_vq.py:154-155,212-243.
+ * Bit-exact twin: oracle/vq_oracle.c (k-ordered fmaf chains).
+ */
+int vq_quantize_f32(const vq_args *a, void *stream);
+
+/* Thin named wrappers: Q must be 1 for vq_nearest_f32. */
+int vq_nearest_f32(const vq_args *a, void *stream);
+int vq_residual_f32(const vq_args *a, void *stream);
+
+/*
+ * Codebook-sharded search, step 1: search only the local shard and emit one packed SIGNED 64-bit key
+ * per row:  hi = order image of the value ("smaller wins", top bit flipped), lo = code index + idx_offset.
+ * `keys[h*M + m]` is combined with atomic MIN, so the caller initialises it (vq_keys_init) and may then
+ * reduce keys across GPUs with ncclMin on int64 (RCCL).  Uses a->x, a->packed, H, M, K, D, metric; Q == 1.
+ */
+int vq_keys_init(int64_t *keys, int64_t n, void *stream);
+int vq_search_keys_f32(const vq_args *a, int64_t idx_offset, int64_t *keys, void *stream);
+
+/*
+ * Step 2: decode the (reduced) keys and finish: idx/best, gather from the natural codebook `a->cb`
+ * (indexed by the GLOBAL code index), straight-through, sq_err.  Q == 1.
+ */
+int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream);
+
+const char *vq_last_error(void);
+int vq_device_info(char *buf, size_t n); /* "gfx950 ... CUs" of the current device */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQ_MI355X_H */

@@ -1,0 +1,201 @@
+"""Generate golden fixtures by IMPORTING THE REFERENCE (this container only; never runs on the GPU box).
+
+    python tests/golden/make_golden.py            # writes tests/golden/data/<case>.npz
+
+The reference (/root/reference, read-only) is pure Python on top of PyTorch.  Its one missing
+dependency, ``einx`` (pinned 0.3.0 in uv.lock, not installed, no network), is used for exactly one
+call -- ``get_at("q [c] d, b n q -> q b n d", codebooks, indices)`` at residual_vq.py:117 -- which is
+provided here by a 4-line local stand-in registered in sys.modules before the import.
+
+Fixtures are data only: seeds/config, the expected indices, losses, checksums and sampled rows of
+the quantized output (plus any randomly initialised projection weights).  No reference source is
+copied.  Metadata records torch version and thread count (goldens come from torch's CPU/MKL path).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+from cases import CASES  # noqa: E402
+from gen import CB_SEED, checksum, l2norm, make_codebook, make_rvq_codebooks, make_x  # noqa: E402
+
+
+def _import_reference():
+    einx = types.ModuleType("einx")
+
+    def get_at(pattern, codebooks, indices):
+        assert pattern == "q [c] d, b n q -> q b n d"
+        return torch.stack([codebooks[q][indices[..., q]] for q in range(codebooks.shape[0])])
+
+    einx.get_at = get_at
+    sys.modules["einx"] = einx
+    sys.path.insert(0, "/root/reference")
+    import vector_quantization as ref  # noqa
+    from vector_quantization import codebooks as ref_cb  # noqa
+
+    return ref, ref_cb
+
+
+def make_mask(b, n):
+    mask = torch.zeros(b, n, dtype=torch.bool)
+    for i in range(b):
+        mask[i, : max(1, n // (i + 1))] = True
+    return mask
+
+
+def sample_rows(t: torch.Tensor, last_dim: int):
+    flat = t.detach().reshape(-1, last_dim)
+    n = flat.shape[0]
+    rows = sorted(set(list(range(min(8, n))) + list(range(max(0, n - 8), n))))
+    return np.asarray(rows, dtype=np.int64), flat[rows].numpy().copy()
+
+
+def run_vq(ref, ref_cb, c):
+    dim, K = c["dim"], c["K"]
+    heads = c.get("heads", 1)
+    separate = c.get("separate_codebook_per_head", False)
+    codebook_dim = c.get("codebook_dim", None)
+    d = codebook_dim if codebook_dim is not None else dim
+    h = heads if separate else 1
+    use_cos = c.get("use_cosine_sim", False)
+    params = ref_cb.CodebookParams(
+        dim=d, codebook_size=K, use_cosine_sim=use_cos,
+        transform_input=c.get("transform_input", "identity"),
+        weights_regularization=c.get("weights_regularization", "identity"),
+    )
+    torch.manual_seed(777)
+    mod = ref.VectorQuantize(dim=dim, codebook_params=params, codebook_dim=codebook_dim, heads=heads,
+                             separate_codebook_per_head=separate, channel_last=c.get("channel_last", True))
+    cb = make_codebook(h, K, d, c["cls"])
+    if c.get("weights_regularization", "identity") == "l2norm":
+        cb = l2norm(cb)
+    with torch.no_grad():
+        mod._codebook.embeddings.copy_(cb)
+    x = make_x(c["x_shape"], c["cls"])
+    stash = {}
+
+    def hook(_m, _inp, out):
+        sim = out[2]
+        stash["best"] = sim.max(dim=-1).values.detach().clone()
+
+    mod._codebook.register_forward_hook(hook)
+    kwargs = {}
+    mask = None
+    if c.get("mask", False):
+        mask = make_mask(x.shape[0], x.shape[1])
+        kwargs["mask"] = mask
+    if c["training"]:
+        mod.train()
+        kwargs["freeze_codebook"] = True
+    else:
+        mod.eval()
+    with torch.no_grad():
+        q, idx, loss = mod(x, **kwargs)
+    arrays = dict(idx=idx.numpy().astype(np.int32), loss=loss.detach().numpy().astype(np.float32),
+                  ref_best=stash["best"].numpy().astype(np.float32))
+    feat_last = q.shape[-1] if c.get("channel_last", True) else None
+    qcl = q if c.get("channel_last", True) else q.movedim(1, -1)
+    rows, vals = sample_rows(qcl, qcl.shape[-1])
+    arrays["q_rows"], arrays["q_vals"] = rows, vals
+    if q.numel() <= 1 << 16:
+        arrays["q_full"] = q.detach().numpy().copy()
+    if mod.has_projections:
+        lin_in = mod.project_in if isinstance(mod.project_in, torch.nn.Linear) else mod.project_in[0]
+        arrays["proj_in_w"] = lin_in.weight.detach().numpy().copy()
+        arrays["proj_in_b"] = lin_in.bias.detach().numpy().copy()
+        arrays["proj_out_w"] = mod.project_out.weight.detach().numpy().copy()
+        arrays["proj_out_b"] = mod.project_out.bias.detach().numpy().copy()
+    meta = dict(x_checksum=checksum(x), cb_checksum=checksum(cb), q_checksum=checksum(q),
+                q_shape=list(q.shape), idx_shape=list(idx.shape))
+    del feat_last
+    return arrays, meta
+
+
+def run_rvq(ref, ref_cb, c):
+    dim, K, Q = c["dim"], c["K"], c["Q"]
+    params = ref_cb.CodebookParams(dim=dim, codebook_size=K)
+    shared = c.get("shared_codebook", False)
+    mod = ref.ResidualVQ(dim=dim, num_quantizers=Q, codebook_params=params, shared_codebook=shared)
+    cbs = make_rvq_codebooks(Q, K, dim, c["cls"])
+    with torch.no_grad():
+        for i, layer in enumerate(mod.layers):
+            layer._codebook.embeddings.copy_(cbs[0 if shared else i][None])
+    x = make_x(c["x_shape"], c["cls"])
+    kwargs = {}
+    if c["training"]:
+        mod.train()
+        kwargs["freeze_codebook"] = True
+    else:
+        mod.eval()
+    if c.get("return_all_codes", False):
+        kwargs["return_all_codes"] = True
+    with torch.no_grad():
+        out = mod(x, **kwargs)
+    q, idx, losses = out[:3]
+    arrays = dict(idx=idx.numpy().astype(np.int32), loss=losses.detach().numpy().astype(np.float32))
+    rows, vals = sample_rows(q, q.shape[-1])
+    arrays["q_rows"], arrays["q_vals"] = rows, vals
+    if q.numel() <= 1 << 16:
+        arrays["q_full"] = q.detach().numpy().copy()
+    if len(out) > 3:
+        arrays["all_codes"] = out[3].detach().numpy().copy()
+    meta = dict(x_checksum=checksum(x), cb_checksum=checksum(cbs), q_checksum=checksum(q),
+                q_shape=list(q.shape), idx_shape=list(idx.shape))
+    return arrays, meta
+
+
+def run_grvq(ref, ref_cb, c):
+    dim, K, Q, G = c["dim"], c["K"], c["Q"], c["groups"]
+    d = dim // G
+    params = ref_cb.CodebookParams(dim=d, codebook_size=K)
+    mod = ref.GroupedResidualVQ(dim=dim, groups=G, num_quantizers=Q, codebook_params=params)
+    all_cbs = []
+    with torch.no_grad():
+        for g, rvq in enumerate(mod.rvqs):
+            cbs = make_rvq_codebooks(Q, K, d, c["cls"], seed=CB_SEED + 100 * g)
+            all_cbs.append(cbs)
+            for i, layer in enumerate(rvq.layers):
+                layer._codebook.embeddings.copy_(cbs[i][None])
+    x = make_x(c["x_shape"], c["cls"])
+    mod.eval()
+    with torch.no_grad():
+        q, idx, losses = mod(x)
+    arrays = dict(idx=idx.numpy().astype(np.int32), loss=losses.detach().numpy().astype(np.float32),
+                  q_full=q.detach().numpy().copy())
+    rows, vals = sample_rows(q, q.shape[-1])
+    arrays["q_rows"], arrays["q_vals"] = rows, vals
+    meta = dict(x_checksum=checksum(x), cb_checksum=checksum(torch.stack(all_cbs)), q_checksum=checksum(q),
+                q_shape=list(q.shape), idx_shape=list(idx.shape))
+    return arrays, meta
+
+
+def main():
+    ref, ref_cb = _import_reference()
+    out_dir = os.path.join(HERE, "data")
+    os.makedirs(out_dir, exist_ok=True)
+    only = set(sys.argv[1:])
+    for c in CASES:
+        if only and c["name"] not in only:
+            continue
+        fn = dict(vq=run_vq, rvq=run_rvq, grvq=run_grvq)[c["kind"]]
+        arrays, meta = fn(ref, ref_cb, c)
+        meta.update(case=c, torch_version=torch.__version__, num_threads=torch.get_num_threads(),
+                    blas="mkl" if torch.backends.mkl.is_available() else "other",
+                    generator="tests/golden/make_golden.py importing /root/reference @ 2024_10_08")
+        arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        path = os.path.join(out_dir, c["name"] + ".npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{c['name']:>20s}  idx{tuple(arrays['idx'].shape)}  loss={arrays['loss'].ravel()[:3]}  "
+              f"{os.path.getsize(path) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

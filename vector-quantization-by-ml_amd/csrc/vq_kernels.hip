@@ -1,0 +1,979 @@
+// vq_kernels.hip -- nearest-codebook search for MI355X (gfx950 / CDNA4).  Hand-written HIP, no
+// compatibility layers.  See DESIGN.md for the full description; summary of the data path:
+//
+//   pack      natural codebook [K, D]  ->  packed image  [Kp][Dp + 4]  (even/odd de-interleave inside
+//             each group of 8 dims, pre-scaled by -2 for Euclid, |c|^2 in float Dp of every row)
+//   search    one wave owns 32 rows of x for the whole sweep; their fp32 values live in REGISTERS as
+//             v_mfma_f32_32x32x2_f32 B-fragments (Dp/2 VGPRs per lane).  The workgroup streams 32-code
+//             tiles of the packed image HBM/L2 -> LDS with global_load_lds (double buffered) and each
+//             wave runs Dp/2 MFMAs per tile (codes on the MFMA i axis, rows on the j axis), then ONE
+//             more MFMA that adds |x|^2 * 1 + 1 * |c|^2  (the two augmented GEMM columns of ATen's
+//             cdist).  The 32x32 result tile is reduced in-lane (a lane holds 16 codes of ONE row),
+//             sqrt only on new record lows, lowest index on ties.
+//   finalize  gather codebook[idx] (natural layout), straight-through, squared-error sums; fused in
+//             the search kernel unless the sweep was split over K (packed 64-bit keys + atomic min).
+//
+// Arithmetic contract (bit-exact twin: oracle/vq_oracle.c): every distance is the k-ordered fmaf
+// chain  fma(1*|c|^2 .. fma(|x|^2*1, fma(x_{D-1}, -2c_{D-1}, ... fma(x_0, -2c_0, 0))))  which is what
+// v_mfma_f32_32x32x2_f32 computes; norms are d-ordered fmaf chains; sqrt is correctly rounded.
+//
+// Reference lines replaced (relative to the reference root): vector_quantization/codebooks.py:386-397,
+// utils/general.py:126-136,159-163, vector_quantize_pytorch.py:261-279,361-364, residual_vq.py:212-243.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vq_mi355x.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kTileCodes = 32;
+constexpr int kPackSlack = 2048;  // floats of over-copy slack behind every packed image
+constexpr int kModeFused = 0;
+constexpr int kModeKeys = 1;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+inline int padded_dim(int D) {
+    if (D <= 32) return 32;
+    if (D <= 64) return 64;
+    if (D <= 128) return 128;
+    if (D <= 256) return 256;
+    if (D <= 512) return 512;
+    return 0;
+}
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------------
+// packed (value, index) keys: signed 64-bit, MIN wins, lowest index on equal values
+// ------------------------------------------------------------------------------------------------
+template <int METRIC>
+__device__ __forceinline__ long long make_key(float v, long long idx) {
+    unsigned b = __float_as_uint(v);
+    unsigned m;
+    if (METRIC == VQ_METRIC_DOT) {
+        unsigned mono = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+        m = ~mono;
+    } else {
+        m = b;  // sqrt distance >= 0: IEEE bits are order preserving
+    }
+    return (long long)(((unsigned long long)(m ^ 0x80000000u) << 32) | (unsigned long long)(unsigned)idx);
+}
+
+__device__ __forceinline__ float key_value(long long key, int metric) {
+    unsigned m = (unsigned)((unsigned long long)key >> 32) ^ 0x80000000u;
+    unsigned b;
+    if (metric == VQ_METRIC_DOT) {
+        unsigned mono = ~m;
+        b = (mono & 0x80000000u) ? (mono ^ 0x80000000u) : ~mono;
+    } else {
+        b = m;
+    }
+    return __uint_as_float(b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack kernel: one thread per packed row
+// ------------------------------------------------------------------------------------------------
+__global__ void vq_pack_kernel(const float *__restrict__ cb, long long cb_stride, int K, int Kp, int D, int DP,
+                               int metric, float *__restrict__ packed, long long pk_stride) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Kp) return;
+    const int RS = DP + 4;
+    const float *src = cb + (long long)blockIdx.y * cb_stride + (long long)k * D;
+    float *dst = packed + (long long)blockIdx.y * pk_stride + (long long)k * RS;
+    const float scale = (metric == VQ_METRIC_EUCLID) ? -2.0f : 1.0f;
+    float cn = 0.0f;
+    for (int g = 0; g < DP / 8; ++g) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = 8 * g + e;
+            v[e] = (k < K && d < D) ? src[d] : 0.0f;
+            cn = fmaf(v[e], v[e], cn);  // d-ordered chain; padded zeros leave it unchanged
+        }
+        f32x4 ev = {scale * v[0], scale * v[2], scale * v[4], scale * v[6]};
+        f32x4 od = {scale * v[1], scale * v[3], scale * v[5], scale * v[7]};
+        *(f32x4 *)(dst + 8 * g) = ev;
+        *(f32x4 *)(dst + 8 * g + 4) = od;
+    }
+    if (k >= K) cn = (metric == VQ_METRIC_EUCLID) ? __builtin_inff() : 0.0f;
+    f32x4 tail = {(metric == VQ_METRIC_EUCLID) ? cn : 0.0f, 0.0f, 0.0f, 0.0f};
+    *(f32x4 *)(dst + DP) = tail;
+}
+
+// ------------------------------------------------------------------------------------------------
+// search kernel
+// ------------------------------------------------------------------------------------------------
+struct SearchParams {
+    const float *x;
+    long long x_rs, x_hs;
+    const float *cb;
+    long long cb_hs, cb_qs;
+    const float *packed;
+    long long pk_hs, pk_qs;
+    float *out;
+    long long out_rs, out_hs;
+    long long *idx;
+    long long idx_rs, idx_hs, idx_qs;
+    float *best;
+    float *loss_part;  // [H * gridDim.x * WAVES][Q] or NULL
+    long long *keys;   // kModeKeys
+    long long idx_offset;
+    long long M;
+    int K, D, Q;
+    int ntiles, tiles_per_split;
+    int mode;
+    int ste;
+    int vec_x;    // x rows may be read as float4 (D % 4 == 0, strides % 4 == 0, 16-B aligned base)
+    int vec_fin;  // finalize may use float4 on x / out / cb
+};
+
+__device__ __forceinline__ void glds16(const float *g, f32x4 *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+template <int DP, int WAVES>
+struct Geo {
+    static constexpr int RS = DP + 4;                       // packed row stride, floats
+    static constexpr int RS4 = RS / 4;
+    static constexpr int TILE_F4 = kTileCodes * RS / 4;     // float4 per 32-code tile image
+    static constexpr int TILE_CHUNKS = (TILE_F4 + 63) / 64; // 1-KiB wave copies per tile (over-copy)
+    static constexpr int BUF_F4 = TILE_CHUNKS * 64;
+    static constexpr int CH = DP < 64 ? DP : 64;            // prologue column chunk
+    static constexpr int XS = CH + 1;                       // prologue scratch row stride, floats (odd)
+    static constexpr int NS = DP / 2;                       // MFMA k-steps
+    static constexpr int MAIN_FLOATS = (2 * BUF_F4 * 4 > WAVES * 32 * XS) ? 2 * BUF_F4 * 4 : WAVES * 32 * XS;
+    static constexpr int NCH4 = DP >= 256 ? DP / 256 : 1;   // float4 chunks per lane in finalize
+    static constexpr int NEL = DP >= 64 ? DP / 64 : 1;      // scalars per lane in finalize
+};
+
+template <int DP, int WAVES, int METRIC, bool MULTI>
+__global__ void __launch_bounds__(WAVES * 64) vq_search_mfma(const SearchParams p) {
+    using G = Geo<DP, WAVES>;
+    constexpr int RS = G::RS, RS4 = G::RS4, CH = G::CH, XS = G::XS, NS = G::NS;
+    constexpr bool EUCLID = (METRIC == VQ_METRIC_EUCLID);
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4 *tile4 = (f32x4 *)smem;
+    int *sidx = (int *)(smem + G::MAIN_FLOATS);  // [WAVES][Q][32]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y;
+    const long long row0 = ((long long)blockIdx.x * WAVES + wave) * 32;
+    const float *xh = p.x + (long long)head * p.x_hs;
+    const float INF = __builtin_inff();
+
+    // ---------------- prologue: this wave's 32 rows -> MFMA fragments in registers ----------------
+    // xf[s] = x[row0 + c][2 s + h]   (lane half h holds the k = h operand of MFMA step s)
+    float xf[NS];
+    {
+        float *xs = smem + wave * (32 * XS);
+#pragma unroll
+        for (int ch = 0; ch < DP / CH; ++ch) {
+#pragma unroll
+            for (int it = 0; it < CH / 8; ++it) {
+                const int f = it * 64 + lane;
+                const int r = f / (CH / 4), c4 = f % (CH / 4);
+                long long grow = row0 + r;
+                if (grow >= p.M) grow = p.M - 1;
+                const int d0 = ch * CH + c4 * 4;
+                const float *src = xh + grow * p.x_rs + d0;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (p.vec_x) {
+                    if (d0 < p.D) v = *(const f32x4 *)src;
+                } else {
+                    if (d0 + 0 < p.D) v.x = src[0];
+                    if (d0 + 1 < p.D) v.y = src[1];
+                    if (d0 + 2 < p.D) v.z = src[2];
+                    if (d0 + 3 < p.D) v.w = src[3];
+                }
+                float *dstp = xs + r * XS + c4 * 4;  // XS is odd: scalar stores, conflict-free strided reads
+                dstp[0] = v.x;
+                dstp[1] = v.y;
+                dstp[2] = v.z;
+                dstp[3] = v.w;
+            }
+            __syncthreads();
+            const float *rp = xs + c * XS + h;  // this lane's row, its k parity
+#pragma unroll
+            for (int u = 0; u < CH / 2; ++u) xf[ch * (CH / 2) + u] = rp[2 * u];
+            __syncthreads();
+        }
+    }
+
+    const long long row = row0 + c;
+    const bool row_ok = row < p.M;
+
+    for (int q = 0; q < (MULTI ? p.Q : 1); ++q) {
+        const float *pk = p.packed + (long long)head * p.pk_hs + (long long)q * p.pk_qs;
+
+        // |x|^2 as the diagonal of X X^T: a k-ordered fmaf chain, identical to the oracle's sumsq_chain
+        float b_aug = 1.0f;
+        if (EUCLID) {
+            f32x16 d = {0};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[s], xf[s], d, 0, 0, 0);
+            const int rsel = (c & 3) + 4 * (c >> 3);
+            float dv = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dv = (r == rsel) ? d[r] : dv;
+            const float ov = __shfl_xor(dv, 32);
+            const float xn = (h == ((c >> 2) & 1)) ? dv : ov;
+            b_aug = h ? 1.0f : xn;  // B[k=0][row] = |x|^2, B[k=1][row] = 1
+        }
+
+        float best_t = INF;                  // Euclid: running min of the clamped squared distance
+        float best_s = EUCLID ? INF : -INF;  // running best value in the compared space
+        int best_i = 0;
+
+        const int t0 = blockIdx.z * p.tiles_per_split;
+        const int t1 = (t0 + p.tiles_per_split < p.ntiles) ? t0 + p.tiles_per_split : p.ntiles;
+
+        // stage the first tile
+#pragma unroll
+        for (int i = 0; i < (G::TILE_CHUNKS + WAVES - 1) / WAVES; ++i) {
+            const int ck = i * WAVES + wave;
+            if (ck < G::TILE_CHUNKS) glds16(pk + ((long long)t0 * G::TILE_F4 + ck * 64 + lane) * 4, tile4 + ck * 64);
+        }
+        __syncthreads();
+
+        for (int t = t0; t < t1; ++t) {
+            const int cur = (t - t0) & 1;
+            if (t + 1 < t1) {
+                f32x4 *nb = tile4 + (cur ^ 1) * G::BUF_F4;
+#pragma unroll
+                for (int i = 0; i < (G::TILE_CHUNKS + WAVES - 1) / WAVES; ++i) {
+                    const int ck = i * WAVES + wave;
+                    if (ck < G::TILE_CHUNKS)
+                        glds16(pk + ((long long)(t + 1) * G::TILE_F4 + ck * 64 + lane) * 4, nb + ck * 64);
+                }
+            }
+            const f32x4 *tb = tile4 + cur * G::BUF_F4;
+            f32x16 acc = {0};
+            {
+                // code fragments: one ds_read_b128 feeds 4 MFMAs (256 cycles); keep PF reads in flight and
+                // pin the order so the scheduler cannot hoist every read to the top (register pressure).
+                constexpr int NG = DP / 8;
+                constexpr int PF = NG < 3 ? NG : 3;
+                const f32x4 *ta = tb + c * RS4 + h;
+                f32x4 a[NG];
+#pragma unroll
+                for (int g = 0; g < PF; ++g) a[g] = ta[2 * g];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + PF < NG) a[g + PF] = ta[2 * (g + PF)];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, xf[4 * g + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, xf[4 * g + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, xf[4 * g + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, xf[4 * g + 3], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            const int cbase = t * kTileCodes + 4 * h;  // code of acc[r] = cbase + (r&3) + 8*(r>>2)
+            if (EUCLID) {
+                const float cnv = ((const float *)tb)[c * RS + DP];
+                const float a_aug = h ? cnv : 1.0f;  // A[code][k=0] = 1, A[code][k=1] = |c|^2
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, acc, 0, 0, 0);
+                if (t * kTileCodes + kTileCodes > p.K) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (cbase + (r & 3) + 8 * (r >> 2) >= p.K) acc[r] = INF;
+                }
+                float tm = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tm = fminf(tm, acc[r]);
+                tm = fmaxf(tm, 0.0f);
+                if (tm < best_t) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float tv = fmaxf(acc[r], 0.0f);  // clamp_min_(0)
+                        if (tv < best_t) {                     // only a new record low can change the argmin
+                            const float s = __fsqrt_rn(tv);
+                            if (s < best_s) {                  // strict: equal sqrt keeps the earlier (lower) code
+                                best_s = s;
+                                best_i = cbase + (r & 3) + 8 * (r >> 2);
+                            }
+                            best_t = tv;
+                        }
+                    }
+                }
+            } else {
+                if (t * kTileCodes + kTileCodes > p.K) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (cbase + (r & 3) + 8 * (r >> 2) >= p.K) acc[r] = -INF;
+                }
+                float tm = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[r]);
+                if (tm > best_s) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (acc[r] > best_s) {
+                            best_s = acc[r];
+                            best_i = cbase + (r & 3) + 8 * (r >> 2);
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // next tile landed (vmcnt(0)) and everybody is done with this one
+        }
+
+        // merge the two lane halves of each row (they saw disjoint codes)
+        {
+            const float os = __shfl_xor(best_s, 32);
+            const int oi = __shfl_xor(best_i, 32);
+            const bool take = EUCLID ? (os < best_s || (os == best_s && oi < best_i))
+                                     : (os > best_s || (os == best_s && oi < best_i));
+            if (take) {
+                best_s = os;
+                best_i = oi;
+            }
+        }
+
+        if (p.mode == kModeKeys) {
+            if (h == 0 && row_ok)
+                atomicMin(p.keys + (long long)head * p.M + row, make_key<METRIC>(best_s, p.idx_offset + best_i));
+            continue;
+        }
+
+        if (h == 0 && row_ok) {
+            const long long o = (long long)head * p.idx_hs + row * p.idx_rs + (long long)q * p.idx_qs;
+            p.idx[o] = best_i;
+            if (p.best) p.best[o] = best_s;
+        }
+        sidx[(wave * p.Q + q) * 32 + c] = best_i;
+
+        // fragment-layout gather of the winner -> next-stage residual  (residual_vq.py:232)
+        if (MULTI && q + 1 < p.Q) {
+            const float *prow = pk + (long long)best_i * RS + 4 * h;
+            const float qs = EUCLID ? -0.5f : 1.0f;  // undo the packed pre-scale (exact)
+            if (p.ste) {
+#pragma unroll
+                for (int g = 0; g < DP / 8; ++g) {
+                    const f32x4 pv = *(const f32x4 *)(prow + 8 * g);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float r = xf[4 * g + u];
+                        const float quant = r + (qs * pv[u] - r);  // the value the layer returns in train mode
+                        xf[4 * g + u] = r - quant;
+                    }
+                    if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the loads in flight (VGPRs)
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < DP / 8; ++g) {
+                    const f32x4 pv = *(const f32x4 *)(prow + 8 * g);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) xf[4 * g + u] = xf[4 * g + u] - qs * pv[u];
+                    if ((g & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    if (p.mode == kModeKeys) return;
+    if (p.out == nullptr && p.loss_part == nullptr) return;
+
+    // ---------------- fused finalize (natural layout) ----------------
+    //   quant_q = c_q[idx_q]                       (eval)      vector_quantize_pytorch.py:227
+    //           = r_q + (c_q[idx_q] - r_q)         (train)     vector_quantize_pytorch.py:273
+    //   r_{q+1} = r_q - quant_q ; out = ((0 + quant_1) + quant_2) + ...   residual_vq.py:232-233
+    //   sq_err_q += (c_q[idx_q] - r_q)^2                                   vector_quantize_pytorch.py:362
+    const bool need_r = p.ste || p.loss_part;
+    float *lerr = (float *)(sidx + WAVES * p.Q * 32) + (wave * p.Q) * 64 + lane;  // [WAVES][Q][64], MULTI only
+    if (MULTI && p.loss_part)
+        for (int q = 0; q < p.Q; ++q) lerr[q * 64] = 0.0f;
+    float e0 = 0.0f;
+    const float *cbh = p.cb + (long long)head * p.cb_hs;
+    float *outh = p.out ? p.out + (long long)head * p.out_hs : nullptr;
+    for (int rr = 0; rr < 32; ++rr) {
+        const long long grow = row0 + rr;
+        if (grow >= p.M) break;  // wave-uniform
+        const float *xr = xh + grow * p.x_rs;
+        float *orow = outh ? outh + grow * p.out_rs : nullptr;
+        if (p.vec_fin) {
+            f32x4 r[G::NCH4], o[G::NCH4];
+#pragma unroll
+            for (int j = 0; j < G::NCH4; ++j) {
+                const int d = 4 * (lane + 64 * j);
+                o[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                r[j] = o[j];
+                if (need_r && d < p.D) r[j] = *(const f32x4 *)(xr + d);
+            }
+            for (int q = 0; q < (MULTI ? p.Q : 1); ++q) {
+                const int i = sidx[(wave * p.Q + q) * 32 + rr];
+                const float *crow = cbh + (long long)q * p.cb_qs + (long long)i * p.D;
+                float e = 0.0f;
+#pragma unroll
+                for (int j = 0; j < G::NCH4; ++j) {
+                    const int d = 4 * (lane + 64 * j);
+                    if (d < p.D) {
+                        const f32x4 cv = *(const f32x4 *)(crow + d);
+                        f32x4 quant = cv;
+                        if (need_r) {
+                            const f32x4 diff = cv - r[j];
+                            e = fmaf(diff.x, diff.x, e);
+                            e = fmaf(diff.y, diff.y, e);
+                            e = fmaf(diff.z, diff.z, e);
+                            e = fmaf(diff.w, diff.w, e);
+                            if (p.ste) quant = r[j] + diff;
+                            r[j] = r[j] - quant;
+                        }
+                        o[j] = o[j] + quant;
+                    }
+                }
+                if (MULTI) {
+                    if (p.loss_part) lerr[q * 64] += e;
+                } else {
+                    e0 += e;
+                }
+            }
+            if (orow) {
+#pragma unroll
+                for (int j = 0; j < G::NCH4; ++j) {
+                    const int d = 4 * (lane + 64 * j);
+                    if (d < p.D) *(f32x4 *)(orow + d) = o[j];
+                }
+            }
+        } else {
+            float r[G::NEL], o[G::NEL];
+#pragma unroll
+            for (int j = 0; j < G::NEL; ++j) {
+                const int d = lane + 64 * j;
+                o[j] = 0.0f;
+                r[j] = (need_r && d < p.D) ? xr[d] : 0.0f;
+            }
+            for (int q = 0; q < (MULTI ? p.Q : 1); ++q) {
+                const int i = sidx[(wave * p.Q + q) * 32 + rr];
+                const float *crow = cbh + (long long)q * p.cb_qs + (long long)i * p.D;
+                float e = 0.0f;
+#pragma unroll
+                for (int j = 0; j < G::NEL; ++j) {
+                    const int d = lane + 64 * j;
+                    if (d < p.D) {
+                        const float cv = crow[d];
+                        float quant = cv;
+                        if (need_r) {
+                            const float diff = cv - r[j];
+                            e = fmaf(diff, diff, e);
+                            if (p.ste) quant = r[j] + diff;
+                            r[j] = r[j] - quant;
+                        }
+                        o[j] = o[j] + quant;
+                    }
+                }
+                if (MULTI) {
+                    if (p.loss_part) lerr[q * 64] += e;
+                } else {
+                    e0 += e;
+                }
+            }
+            if (orow) {
+#pragma unroll
+                for (int j = 0; j < G::NEL; ++j) {
+                    const int d = lane + 64 * j;
+                    if (d < p.D) orow[d] = o[j];
+                }
+            }
+        }
+    }
+    if (p.loss_part) {
+        float *lp = p.loss_part + (((long long)head * gridDim.x + blockIdx.x) * WAVES + wave) * p.Q;
+        for (int q = 0; q < (MULTI ? p.Q : 1); ++q) {
+            float e = MULTI ? lerr[q * 64] : e0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+            if (lane == 0) lp[q] = e;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalar-FMA fallback search: one thread per row, any D / K.  Same chain order as the MFMA kernel
+// (and the oracle), so it doubles as an on-device cross-check.  Emits packed keys.
+// ------------------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ void vq_search_simple(const float *__restrict__ x, long long x_rs, long long x_hs,
+                                 const float *__restrict__ cb, long long cb_hs, long long M, int K, int D,
+                                 long long idx_offset, long long *__restrict__ keys) {
+    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    const int head = blockIdx.y;
+    const float *xr = x + (long long)head * x_hs + row * x_rs;
+    const float *c0 = cb + (long long)head * cb_hs;
+    float xn = 0.0f;
+    if (METRIC == VQ_METRIC_EUCLID)
+        for (int d = 0; d < D; ++d) xn = fmaf(xr[d], xr[d], xn);
+    float best = (METRIC == VQ_METRIC_EUCLID) ? __builtin_inff() : -__builtin_inff();
+    int bi = 0;
+    for (int k = 0; k < K; ++k) {
+        const float *cr = c0 + (long long)k * D;
+        float acc = 0.0f;
+        if (METRIC == VQ_METRIC_EUCLID) {
+            float cn = 0.0f;
+            for (int d = 0; d < D; ++d) {
+                const float cv = cr[d];
+                acc = fmaf(xr[d], -2.0f * cv, acc);
+                cn = fmaf(cv, cv, cn);
+            }
+            acc = fmaf(1.0f, xn, acc);
+            acc = fmaf(cn, 1.0f, acc);
+            const float s = __fsqrt_rn(fmaxf(acc, 0.0f));
+            if (s < best) {
+                best = s;
+                bi = k;
+            }
+        } else {
+            for (int d = 0; d < D; ++d) acc = fmaf(xr[d], cr[d], acc);
+            if (acc > best) {
+                best = acc;
+                bi = k;
+            }
+        }
+    }
+    atomicMin(keys + (long long)head * M + row, make_key<METRIC>(best, idx_offset + bi));
+}
+
+__global__ void vq_keys_init_kernel(long long *keys, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = 0x7FFFFFFFFFFFFFFFll;
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize from keys: one wave per row (grid-strided), natural layout
+// ------------------------------------------------------------------------------------------------
+struct FinalizeParams {
+    const long long *keys;
+    const float *x;
+    long long x_rs, x_hs;
+    const float *cb;
+    long long cb_hs;
+    float *out;
+    long long out_rs, out_hs;
+    long long *idx;
+    long long idx_rs, idx_hs;
+    float *best;
+    float *loss_part;  // [H][gridDim.x * 4]
+    long long M;
+    int D, metric, ste;
+};
+
+__global__ void __launch_bounds__(256) vq_finalize_kernel(const FinalizeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int head = blockIdx.y;
+    const long long nw = (long long)gridDim.x * 4;
+    float e = 0.0f;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < p.M; row += nw) {
+        const long long key = p.keys[(long long)head * p.M + row];
+        const long long i = (long long)(key & 0xFFFFFFFFll);
+        if (lane == 0) {
+            const long long o = (long long)head * p.idx_hs + row * p.idx_rs;
+            if (p.idx) p.idx[o] = i;
+            if (p.best) p.best[o] = key_value(key, p.metric);
+        }
+        const bool need_x = p.ste || p.loss_part;
+        if (!p.out && !p.loss_part) continue;
+        const float *xr = p.x + (long long)head * p.x_hs + row * p.x_rs;
+        const float *crow = p.cb + (long long)head * p.cb_hs + i * p.D;
+        float *orow = p.out ? p.out + (long long)head * p.out_hs + row * p.out_rs : nullptr;
+        for (int d = lane; d < p.D; d += 64) {
+            const float cv = crow[d];
+            float quant = cv;
+            if (need_x) {
+                const float r = xr[d];
+                const float diff = cv - r;
+                e = fmaf(diff, diff, e);
+                if (p.ste) quant = r + diff;
+            }
+            if (orow) orow[d] = quant;
+        }
+    }
+    if (p.loss_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+        if (lane == 0) p.loss_part[((long long)head * gridDim.x + blockIdx.x) * 4 + wave] = e;
+    }
+}
+
+// sq_err[q] = sum over parts of loss_part[part*Q + q]   (double, fixed order)
+__global__ void __launch_bounds__(256) vq_loss_reduce_kernel(const float *__restrict__ part, long long nparts, int Q,
+                                                             double *__restrict__ sq_err) {
+    __shared__ double sh[256];
+    const int q = blockIdx.x;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < nparts; i += 256) s += (double)part[i * Q + q];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sq_err[q] = sh[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct DevInfo {
+    int cus = 0;
+    bool ok = false;
+    char name[128] = "";
+};
+
+const DevInfo &dev_info() {
+    static thread_local DevInfo info;
+    static thread_local int cached_dev = -1;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        info.ok = false;
+        return info;
+    }
+    if (dev != cached_dev) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            info.cus = prop.multiProcessorCount;
+            snprintf(info.name, sizeof(info.name), "%s", prop.gcnArchName);
+            info.ok = true;
+            cached_dev = dev;
+        } else {
+            info.ok = false;
+        }
+    }
+    return info;
+}
+
+template <int DP, int WAVES, int METRIC, bool MULTI>
+int launch_search_t(const SearchParams &p, int H, int splits, hipStream_t s) {
+    using G = Geo<DP, WAVES>;
+    const size_t lds = (size_t)G::MAIN_FLOATS * 4 + (size_t)WAVES * p.Q * 32 * 4 +
+                       ((MULTI && p.loss_part) ? (size_t)WAVES * p.Q * 64 * 4 : 0);
+    if (lds > 160 * 1024) return fail(VQ_E_UNSUPPORTED, "vq_search: LDS budget exceeded (too many residual stages)");
+    auto kern = vq_search_mfma<DP, WAVES, METRIC, MULTI>;
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        attr_done = true;
+    }
+    const long long rows_per_wg = 32ll * WAVES;
+    dim3 grid((unsigned)((p.M + rows_per_wg - 1) / rows_per_wg), (unsigned)H, (unsigned)splits);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_search_mfma launch");
+    return 0;
+}
+
+template <int DP, int WAVES>
+int launch_search_m(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    if (p.Q > 1) {
+        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, true>(p, H, splits, s);
+        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, true>(p, H, splits, s);
+    }
+    if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, false>(p, H, splits, s);
+    return launch_search_t<DP, WAVES, VQ_METRIC_DOT, false>(p, H, splits, s);
+}
+
+int launch_search(int DP, int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    switch (DP) {
+        case 32: return waves == 8 ? launch_search_m<32, 8>(p, H, splits, metric, s) : launch_search_m<32, 4>(p, H, splits, metric, s);
+        case 64: return waves == 8 ? launch_search_m<64, 8>(p, H, splits, metric, s) : launch_search_m<64, 4>(p, H, splits, metric, s);
+        case 128: return waves == 8 ? launch_search_m<128, 8>(p, H, splits, metric, s) : launch_search_m<128, 4>(p, H, splits, metric, s);
+        case 256: return waves == 8 ? launch_search_m<256, 8>(p, H, splits, metric, s) : launch_search_m<256, 4>(p, H, splits, metric, s);
+        case 512: return launch_search_m<512, 4>(p, H, splits, metric, s);
+    }
+    return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
+}
+
+bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+int check_common(const vq_args *a) {
+    if (!a) return fail(VQ_E_BADARG, "vq: null args");
+    if (a->H <= 0 || a->Q <= 0 || a->M < 0 || a->K <= 0 || a->D <= 0) return fail(VQ_E_BADARG, "vq: non-positive size");
+    if (a->metric != VQ_METRIC_EUCLID && a->metric != VQ_METRIC_DOT) return fail(VQ_E_BADARG, "vq: unknown metric");
+    if (!a->x) return fail(VQ_E_BADARG, "vq: x is null");
+    return 0;
+}
+
+// Workspace layout: [keys: H*M int64][loss partials: floats]
+long long ws_keys_bytes(int H, long long M) { return ((long long)H * M * 8 + 255) / 256 * 256; }
+long long ws_loss_floats(int H, long long M, int Q) { return (long long)H * ((M + 31) / 32 + 8) * Q + (long long)H * 8192 + 64; }
+
+void fill_search_params(SearchParams &p, const vq_args *a) {
+    memset(&p, 0, sizeof(p));
+    p.x = a->x; p.x_rs = a->x_rs; p.x_hs = a->x_hs;
+    p.cb = a->cb; p.cb_hs = a->cb_hs; p.cb_qs = a->cb_qs;
+    p.packed = a->packed; p.pk_hs = a->pk_hs; p.pk_qs = a->pk_qs;
+    p.out = a->out; p.out_rs = a->out_rs; p.out_hs = a->out_hs;
+    p.idx = (long long *)a->idx; p.idx_rs = a->idx_rs; p.idx_hs = a->idx_hs; p.idx_qs = a->idx_qs;
+    p.best = a->best;
+    p.M = a->M; p.K = a->K; p.D = a->D; p.Q = a->Q;
+    p.ntiles = (a->K + kTileCodes - 1) / kTileCodes;
+    p.tiles_per_split = p.ntiles;
+    p.ste = (a->flags & VQ_F_STE) ? 1 : 0;
+    p.vec_x = (a->D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x)) ? 1 : 0;
+    p.vec_fin = (p.vec_x && (!a->out || (a->out_rs % 4 == 0 && a->out_hs % 4 == 0 && aligned16(a->out))) &&
+                 (!a->cb || (a->cb_hs % 4 == 0 && a->cb_qs % 4 == 0 && aligned16(a->cb)))) ? 1 : 0;
+}
+
+int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipStream_t s, int *nparts_out) {
+    FinalizeParams f;
+    memset(&f, 0, sizeof(f));
+    f.keys = keys;
+    f.x = a->x; f.x_rs = a->x_rs; f.x_hs = a->x_hs;
+    f.cb = a->cb; f.cb_hs = a->cb_hs;
+    f.out = a->out; f.out_rs = a->out_rs; f.out_hs = a->out_hs;
+    f.idx = (long long *)a->idx; f.idx_rs = a->idx_rs; f.idx_hs = a->idx_hs;
+    f.best = a->best;
+    f.loss_part = loss_part;
+    f.M = a->M; f.D = a->D; f.metric = a->metric; f.ste = (a->flags & VQ_F_STE) ? 1 : 0;
+    long long blocks = (a->M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)blocks, (unsigned)a->H), dim3(256), 0, s, f);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_finalize launch");
+    if (nparts_out) *nparts_out = (int)(blocks * 4 * a->H);
+    return 0;
+}
+
+int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hipStream_t s) {
+    const int DP = padded_dim(a->D);
+    const bool simple = (a->flags & VQ_F_FORCE_SIMPLE) || DP == 0;
+    if (simple) {
+        if (!a->cb) return fail(VQ_E_BADARG, "vq: natural codebook required for the scalar kernel");
+        dim3 grid((unsigned)((a->M + 63) / 64), (unsigned)a->H);
+        if (a->metric == VQ_METRIC_EUCLID)
+            hipLaunchKernelGGL(vq_search_simple<VQ_METRIC_EUCLID>, grid, dim3(64), 0, s, a->x, a->x_rs, a->x_hs, a->cb,
+                               a->cb_hs, a->M, a->K, a->D, idx_offset, keys);
+        else
+            hipLaunchKernelGGL(vq_search_simple<VQ_METRIC_DOT>, grid, dim3(64), 0, s, a->x, a->x_rs, a->x_hs, a->cb,
+                               a->cb_hs, a->M, a->K, a->D, idx_offset, keys);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "vq_search_simple launch");
+        return 0;
+    }
+    if (!a->packed) return fail(VQ_E_BADARG, "vq: packed codebook is null");
+    SearchParams p;
+    fill_search_params(p, a);
+    p.mode = kModeKeys;
+    p.keys = keys;
+    p.idx_offset = idx_offset;
+    p.Q = 1;
+    p.out = nullptr;
+    p.loss_part = nullptr;
+    const DevInfo &di = dev_info();
+    const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+    int waves = (DP == 512) ? 4 : 8;
+    long long wgs = (long long)a->H * ((a->M + 32 * waves - 1) / (32 * waves));
+    if (waves == 8 && wgs < cus) {
+        waves = 4;
+        wgs = (long long)a->H * ((a->M + 127) / 128);
+    }
+    int splits = 1;
+    if (wgs < 2 * cus) {
+        splits = (int)((2 * cus + wgs - 1) / wgs);
+        if (splits > p.ntiles) splits = p.ntiles;
+        if (splits < 1) splits = 1;
+    }
+    p.tiles_per_split = (p.ntiles + splits - 1) / splits;
+    splits = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+    return launch_search(DP, waves, p, a->H, splits, a->metric, s);
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char *vq_last_error(void) { return g_err; }
+
+int vq_device_info(char *buf, size_t n) {
+    const DevInfo &di = dev_info();
+    if (!di.ok) return fail(VQ_E_NODEVICE, "vq: no HIP device");
+    snprintf(buf, n, "%s %d CUs", di.name, di.cus);
+    return 0;
+}
+
+int64_t vq_packed_floats(int K, int D) {
+    if (K <= 0 || D <= 0) return 0;
+    const int DP = padded_dim(D);
+    if (DP == 0) return 4;  // scalar kernel reads the natural codebook
+    return (int64_t)round_up(K, kTileCodes) * (DP + 4) + kPackSlack;
+}
+
+int64_t vq_workspace_bytes(int H, int64_t M, int Q) {
+    if (H <= 0 || M < 0 || Q <= 0) return 0;
+    return ws_keys_bytes(H, M) + ws_loss_floats(H, M, Q) * 4 + 256;
+}
+
+int vq_pack_codebooks_f32(const float *cb, int n_codebooks, int64_t cb_stride, int K, int D, int metric, float *packed,
+                          void *stream) {
+    if (!cb || !packed || n_codebooks <= 0 || K <= 0 || D <= 0) return fail(VQ_E_BADARG, "vq_pack: bad argument");
+    if (metric != VQ_METRIC_EUCLID && metric != VQ_METRIC_DOT) return fail(VQ_E_BADARG, "vq_pack: unknown metric");
+    const int DP = padded_dim(D);
+    if (DP == 0) return 0;  // nothing to pack: the scalar kernel is used for D > 512
+    if (!aligned16(packed)) return fail(VQ_E_BADARG, "vq_pack: packed buffer must be 16-byte aligned");
+    const int Kp = round_up(K, kTileCodes);
+    const long long pk_stride = vq_packed_floats(K, D);
+    hipStream_t s = (hipStream_t)stream;
+    // zero the slack so that over-copies read defined data
+    for (int n = 0; n < n_codebooks; ++n) {
+        hipError_t e = hipMemsetAsync(packed + n * pk_stride + (long long)Kp * (DP + 4), 0, kPackSlack * 4, s);
+        if (e != hipSuccess) return hip_fail(e, "vq_pack memset");
+    }
+    hipLaunchKernelGGL(vq_pack_kernel, dim3((Kp + 63) / 64, n_codebooks), dim3(64), 0, s, cb, (long long)cb_stride, K, Kp,
+                       D, DP, metric, packed, pk_stride);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_pack launch");
+    return 0;
+}
+
+int vq_keys_init(int64_t *keys, int64_t n, void *stream) {
+    if (!keys || n < 0) return fail(VQ_E_BADARG, "vq_keys_init: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(vq_keys_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long long *)keys, (long long)n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_keys_init launch");
+    return 0;
+}
+
+int vq_search_keys_f32(const vq_args *a, int64_t idx_offset, int64_t *keys, void *stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (a->Q != 1) return fail(VQ_E_BADARG, "vq_search_keys: Q must be 1");
+    if (!keys) return fail(VQ_E_BADARG, "vq_search_keys: keys is null");
+    if (idx_offset < 0 || idx_offset + a->K > 0xFFFFFFFFll) return fail(VQ_E_BADARG, "vq_search_keys: index range");
+    if (a->M == 0) return 0;
+    return run_search_keys(a, idx_offset, (long long *)keys, (hipStream_t)stream);
+}
+
+int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (a->Q != 1) return fail(VQ_E_BADARG, "vq_finalize_keys: Q must be 1");
+    if (!keys || !a->cb) return fail(VQ_E_BADARG, "vq_finalize_keys: keys / cb is null");
+    if (a->M == 0) {
+        if (a->sq_err) hipMemsetAsync(a->sq_err, 0, sizeof(double), (hipStream_t)stream);
+        return 0;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float *loss_part = nullptr;
+    if (a->sq_err) {
+        if (!a->workspace || a->workspace_bytes < vq_workspace_bytes(a->H, a->M, 1))
+            return fail(VQ_E_BADARG, "vq_finalize_keys: workspace too small");
+        loss_part = (float *)((char *)a->workspace + ws_keys_bytes(a->H, a->M));
+    }
+    int nparts = 0;
+    rc = run_finalize(a, (const long long *)keys, loss_part, s, &nparts);
+    if (rc) return rc;
+    if (a->sq_err) {
+        hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_part, (long long)nparts, 1, a->sq_err);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
+    }
+    return 0;
+}
+
+int vq_quantize_f32(const vq_args *a, void *stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (!a->idx) return fail(VQ_E_BADARG, "vq_quantize: idx is null");
+    if (!a->cb) return fail(VQ_E_BADARG, "vq_quantize: natural codebook is null");
+    hipStream_t s = (hipStream_t)stream;
+    if (a->M == 0) {
+        if (a->sq_err) hipMemsetAsync(a->sq_err, 0, sizeof(double) * a->Q, s);
+        return 0;
+    }
+    if ((a->sq_err || true) && (!a->workspace || a->workspace_bytes < vq_workspace_bytes(a->H, a->M, a->Q)))
+        return fail(VQ_E_BADARG, "vq_quantize: workspace too small (see vq_workspace_bytes)");
+    long long *keys = (long long *)a->workspace;
+    float *loss_part = (float *)((char *)a->workspace + ws_keys_bytes(a->H, a->M));
+
+    const int DP = padded_dim(a->D);
+    const bool simple = (a->flags & VQ_F_FORCE_SIMPLE) || DP == 0;
+    const DevInfo &di = dev_info();
+    const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+
+    // ---- choose fused (one launch, no K split) or split (keys + finalize) ----
+    bool fused = !simple;
+    int waves = (DP == 512) ? 4 : 8;
+    if (fused) {
+        long long wgs = (long long)a->H * ((a->M + 32 * waves - 1) / (32 * waves));
+        if (waves == 8 && wgs < cus) {
+            waves = 4;
+            wgs = (long long)a->H * ((a->M + 127) / 128);
+        }
+        const int ntiles = (a->K + kTileCodes - 1) / kTileCodes;
+        // few workgroups and a long sweep: splitting K over workgroups fills the chip (Q == 1 only)
+        if (a->Q == 1 && wgs * 2 <= cus && ntiles >= 8) fused = false;
+        if ((a->flags & VQ_F_FORCE_SPLIT) && a->Q == 1) fused = false;
+    }
+
+    if (fused) {
+        if (!a->packed) return fail(VQ_E_BADARG, "vq_quantize: packed codebook is null");
+        SearchParams p;
+        fill_search_params(p, a);
+        p.mode = kModeFused;
+        p.loss_part = a->sq_err ? loss_part : nullptr;
+        rc = launch_search(DP, waves, p, a->H, 1, a->metric, s);
+        if (rc) return rc;
+        if (a->sq_err) {
+            const long long rows_per_wg = 32ll * waves;
+            const long long nparts = (long long)a->H * ((a->M + rows_per_wg - 1) / rows_per_wg) * waves;
+            hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(a->Q), dim3(256), 0, s, loss_part, nparts, a->Q, a->sq_err);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
+        }
+        return 0;
+    }
+
+    if (a->Q != 1) return fail(VQ_E_UNSUPPORTED, "vq_quantize: residual stages need the MFMA kernel (D <= 512)");
+    rc = vq_keys_init((int64_t *)keys, (int64_t)a->H * a->M, stream);
+    if (rc) return rc;
+    rc = run_search_keys(a, 0, keys, s);
+    if (rc) return rc;
+    int nparts = 0;
+    rc = run_finalize(a, keys, a->sq_err ? loss_part : nullptr, s, &nparts);
+    if (rc) return rc;
+    if (a->sq_err) {
+        hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_part, (long long)nparts, 1, a->sq_err);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
+    }
+    return 0;
+}
+
+int vq_nearest_f32(const vq_args *a, void *stream) {
+    if (a && a->Q != 1) return fail(VQ_E_BADARG, "vq_nearest_f32: Q must be 1");
+    return vq_quantize_f32(a, stream);
+}
+
+int vq_residual_f32(const vq_args *a, void *stream) { return vq_quantize_f32(a, stream); }
+
+}  // extern "C"

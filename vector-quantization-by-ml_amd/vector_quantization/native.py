@@ -1,0 +1,263 @@
+"""ctypes binding of libvq_mi355x.so (C ABI declared in include/vq_mi355x.h).
+
+There is deliberately NO fallback: if the HIP library is missing or the tensors are not on a ROCm
+device, every entry point raises.  PyTorch is used only for device memory and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import torch
+
+EUCLID = 0
+DOT = 1
+
+F_STE = 1
+F_FORCE_SIMPLE = 2
+F_FORCE_SPLIT = 4
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get(
+    "VQ_MI355X_LIB", os.path.join(os.path.dirname(_PKG_DIR), "lib", "libvq_mi355x.so")
+)
+
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_vp = ctypes.c_void_p
+
+
+class VqArgs(ctypes.Structure):
+    """Mirror of ``struct vq_args`` (include/vq_mi355x.h)."""
+
+    _fields_ = [
+        ("H", _i32), ("Q", _i32), ("M", _i64), ("K", _i32), ("D", _i32), ("metric", _i32), ("flags", ctypes.c_uint32),
+        ("x", _vp), ("x_rs", _i64), ("x_hs", _i64),
+        ("cb", _vp), ("cb_hs", _i64), ("cb_qs", _i64),
+        ("packed", _vp), ("pk_hs", _i64), ("pk_qs", _i64),
+        ("out", _vp), ("out_rs", _i64), ("out_hs", _i64),
+        ("idx", _vp), ("idx_rs", _i64), ("idx_hs", _i64), ("idx_qs", _i64),
+        ("best", _vp),
+        ("sq_err", _vp),
+        ("workspace", _vp), ("workspace_bytes", _i64),
+    ]
+
+
+class NativeUnavailable(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (once).  Raises NativeUnavailable if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise NativeUnavailable(
+                f"{_LIB_PATH} not found: build it with vector-quantization-by-ml_amd/build.sh "
+                "(or __graft_entry__.build()).  There is no CPU/PyTorch fallback for the search path."
+            )
+        lib = ctypes.CDLL(_LIB_PATH)
+        ap = ctypes.POINTER(VqArgs)
+        lib.vq_last_error.restype = ctypes.c_char_p
+        lib.vq_packed_floats.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.vq_packed_floats.restype = _i64
+        lib.vq_workspace_bytes.argtypes = [ctypes.c_int, _i64, ctypes.c_int]
+        lib.vq_workspace_bytes.restype = _i64
+        lib.vq_pack_codebooks_f32.argtypes = [_vp, ctypes.c_int, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]
+        lib.vq_pack_codebooks_f32.restype = ctypes.c_int
+        for name in ("vq_quantize_f32", "vq_nearest_f32", "vq_residual_f32"):
+            fn = getattr(lib, name)
+            fn.argtypes = [ap, _vp]
+            fn.restype = ctypes.c_int
+        lib.vq_keys_init.argtypes = [_vp, _i64, _vp]
+        lib.vq_keys_init.restype = ctypes.c_int
+        lib.vq_search_keys_f32.argtypes = [ap, _i64, _vp, _vp]
+        lib.vq_search_keys_f32.restype = ctypes.c_int
+        lib.vq_finalize_keys_f32.argtypes = [ap, _vp, _vp]
+        lib.vq_finalize_keys_f32.restype = ctypes.c_int
+        lib.vq_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        lib.vq_device_info.restype = ctypes.c_int
+        _lib = lib
+    return _lib
+
+
+EXPORTED_SYMBOLS = (
+    "vq_packed_floats", "vq_pack_codebooks_f32", "vq_workspace_bytes", "vq_quantize_f32", "vq_nearest_f32",
+    "vq_residual_f32", "vq_keys_init", "vq_search_keys_f32", "vq_finalize_keys_f32", "vq_last_error",
+    "vq_device_info",
+)
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().vq_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NativeUnavailable(
+                "the nearest-codebook search runs only on a ROCm device (MI355X): got a CPU tensor and there "
+                "is no CPU fallback in this package"
+            )
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def device_info() -> str:
+    buf = ctypes.create_string_buffer(256)
+    _check(load().vq_device_info(buf, 256), "vq_device_info")
+    return buf.value.decode()
+
+
+def packed_floats(K: int, D: int) -> int:
+    return int(load().vq_packed_floats(K, D))
+
+
+def pack_codebooks(cb: torch.Tensor, metric: int) -> torch.Tensor:
+    """cb [..., K, D] contiguous fp32 on the GPU -> packed images [n, packed_floats(K, D)]."""
+    _require_gpu(cb)
+    assert cb.dtype == torch.float32 and cb.is_contiguous()
+    K, D = cb.shape[-2], cb.shape[-1]
+    n = cb.numel() // (K * D)
+    pf = packed_floats(K, D)
+    packed = torch.empty((n, pf), dtype=torch.float32, device=cb.device)
+    with torch.cuda.device(cb.device):
+        _check(load().vq_pack_codebooks_f32(cb.data_ptr(), n, K * D, K, D, metric, packed.data_ptr(),
+                                            _stream_ptr(cb.device)), "vq_pack_codebooks_f32")
+    return packed
+
+
+def _workspace(H: int, M: int, Q: int, device) -> torch.Tensor:
+    nbytes = int(load().vq_workspace_bytes(H, M, Q))
+    return torch.empty((nbytes + 15) // 16 * 2, dtype=torch.float64, device=device)
+
+
+def _row_strides(t: torch.Tensor):
+    """t is [H, M, D] (any strides, last dim contiguous) -> (row_stride, head_stride) in elements."""
+    assert t.dim() == 3 and (t.shape[-1] == 1 or t.stride(-1) == 1), "last dim must be contiguous"
+    return int(t.stride(1)), int(t.stride(0))
+
+
+def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bool = False, want_out: bool = True,
+             want_sq_err: bool = False, want_best: bool = True, packed: torch.Tensor | None = None,
+             stages_share_codebook: bool = False, flags: int = 0, out: torch.Tensor | None = None):
+    """The hot path through the C ABI.
+
+    x   [H, M, D] fp32 (rows may be strided, last dim contiguous)
+    cb  [H, Q, K, D] fp32 contiguous natural codebooks ([H, 1, K, D] with stages_share_codebook)
+    returns dict(out [H, M, D] | None, idx [H, M, Q] int64, best [H, M, Q] | None, sq_err [Q] float64 | None)
+    """
+    _require_gpu(x, cb)
+    assert x.dtype == torch.float32 and cb.dtype == torch.float32
+    assert x.dim() == 3 and cb.dim() == 4 and cb.is_contiguous()
+    H, M, D = x.shape
+    Hc, Qc, K, Dc = cb.shape
+    assert Hc == H and Dc == D
+    Q = Qc
+    dev = x.device
+    if packed is None:
+        packed = pack_codebooks(cb, metric)
+    pf = packed.shape[-1]
+    x_rs, x_hs = _row_strides(x)
+    idx = torch.empty((H, M, Q), dtype=torch.int64, device=dev)
+    best = torch.empty((H, M, Q), dtype=torch.float32, device=dev) if want_best else None
+    if want_out:
+        if out is None:
+            out = torch.empty((H, M, D), dtype=torch.float32, device=dev)
+        o_rs, o_hs = _row_strides(out)
+    else:
+        out, o_rs, o_hs = None, 0, 0
+    sq_err = torch.empty((Q,), dtype=torch.float64, device=dev) if want_sq_err else None
+    ws = _workspace(H, M, Q, dev)
+    a = VqArgs()
+    a.H, a.Q, a.M, a.K, a.D, a.metric = H, Q, M, K, D, metric
+    a.flags = flags | (F_STE if ste else 0)
+    a.x, a.x_rs, a.x_hs = x.data_ptr(), x_rs, x_hs
+    a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), Qc * K * D, (0 if stages_share_codebook else K * D)
+    a.packed, a.pk_hs, a.pk_qs = packed.data_ptr(), Qc * pf, (0 if stages_share_codebook else pf)
+    a.out, a.out_rs, a.out_hs = (out.data_ptr() if out is not None else None), o_rs, o_hs
+    a.idx, a.idx_rs, a.idx_hs, a.idx_qs = idx.data_ptr(), Q, M * Q, 1
+    a.best = best.data_ptr() if best is not None else None
+    a.sq_err = sq_err.data_ptr() if sq_err is not None else None
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8
+    with torch.cuda.device(dev):
+        _check(load().vq_quantize_f32(ctypes.byref(a), _stream_ptr(dev)), "vq_quantize_f32")
+    return dict(out=out, idx=idx, best=best, sq_err=sq_err)
+
+
+def keys_init(keys: torch.Tensor):
+    _require_gpu(keys)
+    assert keys.dtype == torch.int64 and keys.is_contiguous()
+    with torch.cuda.device(keys.device):
+        _check(load().vq_keys_init(keys.data_ptr(), keys.numel(), _stream_ptr(keys.device)), "vq_keys_init")
+
+
+def search_keys(x: torch.Tensor, cb: torch.Tensor, keys: torch.Tensor, *, metric: int = EUCLID, idx_offset: int = 0,
+                packed: torch.Tensor | None = None, flags: int = 0):
+    """Shard-local search: atomically MIN-combine packed (value, idx + idx_offset) keys into keys [H, M]."""
+    _require_gpu(x, cb, keys)
+    assert x.dim() == 3 and cb.dim() == 3 and cb.is_contiguous() and keys.dtype == torch.int64
+    H, M, D = x.shape
+    _, K, _ = cb.shape
+    assert keys.shape == (H, M) and keys.is_contiguous()
+    if packed is None:
+        packed = pack_codebooks(cb, metric)
+    x_rs, x_hs = _row_strides(x)
+    a = VqArgs()
+    a.H, a.Q, a.M, a.K, a.D, a.metric, a.flags = H, 1, M, K, D, metric, flags
+    a.x, a.x_rs, a.x_hs = x.data_ptr(), x_rs, x_hs
+    a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), K * D, 0
+    a.packed, a.pk_hs, a.pk_qs = packed.data_ptr(), packed.shape[-1], 0
+    with torch.cuda.device(x.device):
+        _check(load().vq_search_keys_f32(ctypes.byref(a), idx_offset, keys.data_ptr(), _stream_ptr(x.device)),
+               "vq_search_keys_f32")
+
+
+def finalize_keys(x: torch.Tensor, cb_full: torch.Tensor, keys: torch.Tensor, *, metric: int = EUCLID, ste: bool = False,
+                  want_sq_err: bool = False, out: torch.Tensor | None = None, want_out: bool = True):
+    """Decode reduced keys and gather from the FULL natural codebook cb_full [H, K_total, D]."""
+    _require_gpu(x, cb_full, keys)
+    H, M, D = x.shape
+    K = cb_full.shape[1]
+    dev = x.device
+    idx = torch.empty((H, M), dtype=torch.int64, device=dev)
+    best = torch.empty((H, M), dtype=torch.float32, device=dev)
+    if want_out and out is None:
+        out = torch.empty((H, M, D), dtype=torch.float32, device=dev)
+    sq_err = torch.empty((1,), dtype=torch.float64, device=dev) if want_sq_err else None
+    ws = _workspace(H, M, 1, dev)
+    x_rs, x_hs = _row_strides(x)
+    a = VqArgs()
+    a.H, a.Q, a.M, a.K, a.D, a.metric = H, 1, M, K, D, metric
+    a.flags = F_STE if ste else 0
+    a.x, a.x_rs, a.x_hs = x.data_ptr(), x_rs, x_hs
+    a.cb, a.cb_hs, a.cb_qs = cb_full.data_ptr(), K * D, 0
+    if out is not None:
+        o_rs, o_hs = _row_strides(out)
+        a.out, a.out_rs, a.out_hs = out.data_ptr(), o_rs, o_hs
+    a.idx, a.idx_rs, a.idx_hs, a.idx_qs = idx.data_ptr(), 1, M, 0
+    a.best = best.data_ptr()
+    a.sq_err = sq_err.data_ptr() if sq_err is not None else None
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8
+    with torch.cuda.device(dev):
+        _check(load().vq_finalize_keys_f32(ctypes.byref(a), keys.data_ptr(), _stream_ptr(dev)), "vq_finalize_keys_f32")
+    return dict(out=out, idx=idx, best=best, sq_err=sq_err)
