@@ -58,7 +58,7 @@ def test_single_stage_bit_exact(oracle, H, M, K, D, cls, metric):
     assert np.array_equal(got["best"][..., 0].numpy().view(np.uint32), ref["best"].view(np.uint32)), "distances differ"
     np.testing.assert_array_equal(got["out"].numpy(), ref["out"])
     np.testing.assert_allclose(got["sq_err"].numpy()[0], ref["sq_err"], rtol=1e-6)
-    if cls == "Gdup" and K >= 2:
+    if cls == "Gdup" and K >= 2 and K % 2 == 0:
         assert idx.max() < max(K // 2, 1)
 
 

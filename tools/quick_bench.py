@@ -1,0 +1,38 @@
+"""Quick kernel timing (dev tool): python tools/quick_bench.py [M K D H Q] ..."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vector-quantization-by-ml_amd"), os.path.join(ROOT, "tests", "golden")]
+import torch
+from vector_quantization import native
+
+def bench(M, K, D, H=1, Q=1, iters=10, flags=0, want_out=True):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu"); g.manual_seed(0)
+    x = torch.randn((H, M, D), generator=g).to(dev)
+    cb = torch.randn((H, Q, K, D), generator=g).to(dev)
+    packed = native.pack_codebooks(cb, 0)
+    for _ in range(3):
+        native.quantize(x, cb, packed=packed, flags=flags, want_out=want_out)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        native.quantize(x, cb, packed=packed, flags=flags, want_out=want_out)
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    flops = 2.0 * H * M * K * D * Q
+    print(f"M={M} K={K} D={D} H={H} Q={Q} flags={flags}: {ms:.3f} ms  {H*M/ms/1e3:.2f} Mrows/s  {flops/ms/1e9:.1f} TFLOP/s ({flops/ms/1e9/157.3*100:.1f}% of 157.3)")
+    # pack time
+    s.record()
+    for _ in range(iters):
+        native.pack_codebooks(cb, 0)
+    e.record(); torch.cuda.synchronize()
+    print(f"    pack: {s.elapsed_time(e)/iters*1e3:.1f} us")
+
+if __name__ == "__main__":
+    print(native.device_info())
+    cfgs = [(262144, 1024, 256), (262144, 8192, 256), (65536, 8192, 64, 8), (65536, 1024, 256, 1, 8), (8192, 65536, 512), (8192, 256, 64)]
+    if len(sys.argv) > 1:
+        cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
+    for c in cfgs:
+        bench(*c)

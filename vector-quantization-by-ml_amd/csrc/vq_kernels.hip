@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(WAVES * 64) vq_search_mfma(const SearchParams 
                     for (int r = 0; r < 16; ++r) {
                         const float tv = fmaxf(acc[r], 0.0f);  // clamp_min_(0)
                         if (tv < best_t) {                     // only a new record low can change the argmin
-                            const float s = __fsqrt_rn(tv);
+                            const float s = sqrtf(tv);
                             if (s < best_s) {                  // strict: equal sqrt keeps the earlier (lower) code
                                 best_s = s;
                                 best_i = cbase + (r & 3) + 8 * (r >> 2);
@@ -540,7 +540,7 @@ __global__ void vq_search_simple(const float *__restrict__ x, long long x_rs, lo
             }
             acc = fmaf(1.0f, xn, acc);
             acc = fmaf(cn, 1.0f, acc);
-            const float s = __fsqrt_rn(fmaxf(acc, 0.0f));
+            const float s = sqrtf(fmaxf(acc, 0.0f));
             if (s < best) {
                 best = s;
                 bi = k;
