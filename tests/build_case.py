@@ -1,0 +1,80 @@
+"""Build the drop-in module + inputs for a golden case (the 'harness counterpart' of SURVEY 8c)."""
+from __future__ import annotations
+
+import torch
+
+from gen import CB_SEED, l2norm, make_codebook, make_rvq_codebooks, make_x
+
+
+def make_mask(b, n):
+    mask = torch.zeros(b, n, dtype=torch.bool)
+    for i in range(b):
+        mask[i, : max(1, n // (i + 1))] = True
+    return mask
+
+
+def build(case, arrays=None, device="cpu"):
+    """-> (module, x, forward_kwargs, codebook_tensor)."""
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    kind = case["kind"]
+    x = make_x(case["x_shape"], case["cls"])
+    kwargs = {}
+    if kind == "vq":
+        dim, K = case["dim"], case["K"]
+        heads = case.get("heads", 1)
+        separate = case.get("separate_codebook_per_head", False)
+        codebook_dim = case.get("codebook_dim", None)
+        d = codebook_dim if codebook_dim is not None else dim
+        h = heads if separate else 1
+        params = CodebookParams(dim=d, codebook_size=K, use_cosine_sim=case.get("use_cosine_sim", False),
+                                transform_input=case.get("transform_input", "identity"),
+                                weights_regularization=case.get("weights_regularization", "identity"))
+        mod = vq.VectorQuantize(dim=dim, codebook_params=params, codebook_dim=codebook_dim, heads=heads,
+                                separate_codebook_per_head=separate, channel_last=case.get("channel_last", True))
+        cb = make_codebook(h, K, d, case["cls"])
+        if case.get("weights_regularization", "identity") == "l2norm":
+            cb = l2norm(cb)
+        with torch.no_grad():
+            mod._codebook.embeddings.copy_(cb)
+            if mod.has_projections:
+                assert arrays is not None
+                mod.project_in.weight.copy_(torch.from_numpy(arrays["proj_in_w"]))
+                mod.project_in.bias.copy_(torch.from_numpy(arrays["proj_in_b"]))
+                mod.project_out.weight.copy_(torch.from_numpy(arrays["proj_out_w"]))
+                mod.project_out.bias.copy_(torch.from_numpy(arrays["proj_out_b"]))
+        if case.get("mask", False):
+            kwargs["mask"] = make_mask(x.shape[0], x.shape[1]).to(device)
+    elif kind == "rvq":
+        dim, K, Q = case["dim"], case["K"], case["Q"]
+        shared = case.get("shared_codebook", False)
+        mod = vq.ResidualVQ(dim=dim, num_quantizers=Q, codebook_params=CodebookParams(dim=dim, codebook_size=K),
+                            shared_codebook=shared)
+        cb = make_rvq_codebooks(Q, K, dim, case["cls"])
+        with torch.no_grad():
+            for i, layer in enumerate(mod.layers):
+                layer._codebook.embeddings.copy_(cb[0 if shared else i][None])
+        if case.get("return_all_codes", False):
+            kwargs["return_all_codes"] = True
+    elif kind == "grvq":
+        dim, K, Q, G = case["dim"], case["K"], case["Q"], case["groups"]
+        d = dim // G
+        mod = vq.GroupedResidualVQ(dim=dim, groups=G, num_quantizers=Q,
+                                   codebook_params=CodebookParams(dim=d, codebook_size=K))
+        cbs = []
+        with torch.no_grad():
+            for g, rvq in enumerate(mod.rvqs):
+                c = make_rvq_codebooks(Q, K, d, case["cls"], seed=CB_SEED + 100 * g)
+                cbs.append(c)
+                for i, layer in enumerate(rvq.layers):
+                    layer._codebook.embeddings.copy_(c[i][None])
+        cb = torch.stack(cbs)
+    else:
+        raise ValueError(kind)
+    if case["training"]:
+        mod.train()
+        kwargs["freeze_codebook"] = True
+    else:
+        mod.eval()
+    return mod.to(device), x.to(device), kwargs, cb

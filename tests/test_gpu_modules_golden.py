@@ -1,0 +1,133 @@
+"""GPU: the drop-in modules on cuda:0 (native HIP backend, no checker installed) against the golden vectors
+captured from the reference, plus module-level behaviours (autograd, EMA bookkeeping, state_dict names)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from build_case import build  # noqa: E402
+from cases import CASES  # noqa: E402
+from check_case import compare  # noqa: E402
+from helpers import load_golden  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def _native_backend():
+    from vector_quantization import native, search
+
+    native.load()
+    search.set_backend(None)
+    assert search.get_backend().name == "hip-gfx950"
+    yield
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_module_matches_reference_golden_on_gpu(case):
+    arrays, meta = load_golden(case["name"])
+    mod, x, kwargs, cb = build(case, arrays, device="cuda:0")
+    with torch.no_grad():
+        outputs = mod(x, **kwargs)
+    torch.cuda.synchronize()
+    compare(case, arrays, meta, outputs, x, cb)
+
+
+def test_gpu_equals_oracle_backend_on_all_cases(oracle):
+    """Same modules, same inputs: native backend on the GPU vs checker backend on the CPU -> identical idx / q."""
+    from helpers import OracleBackend
+    from vector_quantization import search
+
+    for case in CASES:
+        if case["name"] in ("cfg5_S",):
+            continue
+        arrays, _ = load_golden(case["name"])
+        mod, x, kwargs, _ = build(case, arrays, device="cuda:0")
+        with torch.no_grad():
+            got = mod(x, **kwargs)
+        search.set_backend(OracleBackend)
+        try:
+            mod_c, x_c, kwargs_c, _ = build(case, arrays, device="cpu")
+            with torch.no_grad():
+                ref = mod_c(x_c, **kwargs_c)
+        finally:
+            search.set_backend(None)
+        np.testing.assert_array_equal(got[1].cpu().numpy(), ref[1].numpy(), err_msg=case["name"])
+        if not mod.__dict__.get("has_projections", False) and not case.get("codebook_dim") and case["name"] != "proj_mh":
+            np.testing.assert_array_equal(got[0].cpu().numpy(), ref[0].numpy(), err_msg=case["name"])
+        np.testing.assert_allclose(got[2].cpu().numpy(), ref[2].numpy(), atol=1e-6, err_msg=case["name"])
+
+
+def test_autograd_straight_through_and_commitment():
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(0)
+    dev = "cuda:0"
+    mod = vq.VectorQuantize(dim=32, codebook_params=CodebookParams(dim=32, codebook_size=64), commitment_weight=0.25).to(dev)
+    mod.train()
+    x = torch.randn(3, 17, 32, device=dev, requires_grad=True)
+    q, idx, loss = mod(x, freeze_codebook=True)
+    w = torch.randn_like(q)
+    ((q * w).sum() + 3.0 * loss.sum()).backward()
+    codes = mod._codebook.embeddings[0][idx]
+    expect = w + 3.0 * 0.25 * 2.0 * (x.detach() - codes) / x.numel()
+    torch.testing.assert_close(x.grad, expect, rtol=1e-5, atol=1e-6)
+
+
+def test_ema_update_matches_one_hot_formulation():
+    """Training-mode bookkeeping after the hot path: same statistics as the reference's one-hot products."""
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(1)
+    dev = "cuda:0"
+    K, D = 32, 16
+    mod = vq.VectorQuantize(dim=D, codebook_params=CodebookParams(dim=D, codebook_size=K, threshold_ema_dead_code=0,
+                                                                decay=0.8)).to(dev)
+    with torch.no_grad():
+        mod._codebook.embeddings.copy_(torch.randn(1, K, D))
+        mod._codebook.embed_avg.copy_(mod._codebook.embeddings)
+    emb0 = mod._codebook.embeddings.clone()
+    avg0 = mod._codebook.embed_avg.clone()
+    mod.train()
+    x = torch.randn(4, 50, D, device=dev)
+    with torch.no_grad():
+        _, idx, _ = mod(x)
+    onehot = torch.nn.functional.one_hot(idx.reshape(-1), K).float()
+    cs = torch.zeros(1, K, device=dev).lerp(onehot.sum(0)[None], 0.2)
+    avg = avg0.lerp((onehot.t() @ x.reshape(-1, D))[None], 0.2)
+    tot = cs.sum(-1, keepdim=True)
+    sm = (cs + 1e-5) / (tot + K * 1e-5) * tot
+    torch.testing.assert_close(mod._codebook.cluster_size, cs, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(mod._codebook.embed_avg, avg, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(mod._codebook.embeddings, avg / sm[..., None], rtol=1e-4, atol=1e-5)
+    assert not torch.equal(emb0, mod._codebook.embeddings)
+
+
+def test_state_dict_names_are_the_reference_checkpoint_format():
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    mod = vq.VectorQuantize(dim=16, codebook_params=CodebookParams(dim=16, codebook_size=8))
+    assert set(mod.state_dict().keys()) == {"_codebook.cluster_size", "_codebook.embed_avg", "_codebook.embeddings"}
+    rvq = vq.ResidualVQ(dim=16, num_quantizers=2, codebook_params=CodebookParams(dim=16, codebook_size=8))
+    assert "layers.1._codebook.embeddings" in rvq.state_dict()
+
+
+def test_kmeans_init_runs_on_native_search():
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams, KmeansParameters
+
+    torch.manual_seed(2)
+    dev = "cuda:0"
+    mod = vq.VectorQuantize(dim=16, codebook_params=CodebookParams(dim=16, codebook_size=8, initialization_by_kmeans=True,
+                                                                 kmeans_params=KmeansParameters(iter=5))).to(dev)
+    mod.train()
+    centers = torch.randn(8, 16, device=dev) * 5
+    x = (centers[torch.randint(0, 8, (4, 100), device=dev)] + 0.01 * torch.randn(4, 100, 16, device=dev))
+    q, idx, loss = mod(x)
+    assert q.shape == x.shape and idx.shape == x.shape[:-1]
+    assert mod._codebook.is_initialized
+    assert float(mod._codebook.cluster_size.sum()) > 0

@@ -1,0 +1,266 @@
+"""``Codebook``: the stateful holder of the code vectors, re-written around ONE native search op.
+
+Mirrors the constructor signature, buffer names (= checkpoint format: ``embeddings``, ``embed_avg``,
+``cluster_size``) and return convention of the reference class
+(/root/reference/vector_quantization/codebooks.py:81-435), but never materialises the ``[h, M, K]``
+similarity / one-hot tensors the reference builds on every call (codebooks.py:386-390,
+utils/general.py:129): search + gather (+ straight-through + squared error) is a single HIP launch.
+
+What is native here: the forward search/gather (``search.quantize_rows``).  What is plain PyTorch on
+the same device (training-state bookkeeping that comes AFTER the hot path): EMA statistics,
+dead-code re-seeding, k-means seeding (which reuses the native search for its assignment step).
+"""
+from __future__ import annotations
+
+from dataclasses import asdict, is_dataclass
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from . import search
+from .params import GumbelParams, KmeansParameters
+
+
+def _identity(t):
+    return t
+
+
+def _unit_rows(t):
+    return F.normalize(t, p=2, dim=-1)
+
+
+_ROW_TRANSFORMS = {"identity": _identity, "l2norm": _unit_rows}
+
+
+def _row_transform(name: str, what: str):
+    if name not in _ROW_TRANSFORMS:
+        # the reference does `raise "<str>"`, which surfaces as a TypeError (codebooks.py:110,117)
+        raise TypeError(f"The option {name} for {what} is not implemented")
+    return _ROW_TRANSFORMS[name]
+
+
+def _default_codebook(h: int, k: int, d: int) -> torch.Tensor:
+    """Same distribution as the reference's default (kaiming_uniform_ on [h, K, D]: fan_in = K * D)."""
+    t = torch.empty(h, k, d)
+    nn.init.kaiming_uniform_(t)
+    return t
+
+
+def _pick_rows(rows: torch.Tensor, count: int) -> torch.Tensor:
+    """`count` rows of a [N, D] tensor: a random subset when N >= count, else draws with replacement."""
+    n = rows.shape[0]
+    if n >= count:
+        sel = torch.randperm(n, device=rows.device)[:count]
+    else:
+        sel = torch.randint(0, n, (count,), device=rows.device)
+    return rows[sel]
+
+
+class Codebook(nn.Module):
+    def __init__(
+        self,
+        dim,
+        codebook_size,
+        num_codebooks=1,
+        initialization_by_kmeans: bool = False,
+        kmeans_params: KmeansParameters = None,
+        decay: float = 0.8,
+        eps_for_smoothing: float = 1e-5,
+        threshold_ema_dead_code: int = 2,
+        reset_cluster_size: int = None,
+        use_ddp: bool = False,
+        distributed_replace_codes: bool = True,
+        learnable_codebook: bool = False,
+        gumbel_params: GumbelParams = None,
+        ema_update: bool = True,
+        use_affine: bool = False,
+        affine_params=None,
+        transform_input: str = "identity",
+        use_cosine_sim: bool = False,
+        weights_regularization: str = "identity",
+    ):
+        super().__init__()
+        self.transform_input = _row_transform(transform_input, "transform input function")
+        self.weights_regularization = _row_transform(weights_regularization, "weights regularization")
+        if use_affine:
+            raise NotImplementedError("affine re-parameterisation is outside the MI355X hot-path build (SURVEY 2, #6)")
+
+        self.dim = dim
+        self.codebook_size = codebook_size
+        self.num_codebooks = num_codebooks
+        self.use_cosine_sim = use_cosine_sim
+        self.metric = search.DOT if use_cosine_sim else search.EUCLID
+        self.decay = decay
+        self.ema_update = ema_update
+        self.eps_for_smoothing = eps_for_smoothing
+        self.threshold_ema_dead_code = threshold_ema_dead_code
+        self.reset_cluster_size = threshold_ema_dead_code if reset_cluster_size is None else reset_cluster_size
+        self.use_ddp = use_ddp
+        self.distributed_replace_codes = distributed_replace_codes
+        self.learnable_codebook = learnable_codebook
+        self.use_affine = False
+
+        if kmeans_params is None:
+            kmeans_params = KmeansParameters() if initialization_by_kmeans else None
+        self.kmeans_params = asdict(kmeans_params) if is_dataclass(kmeans_params) else kmeans_params
+        if gumbel_params is None:
+            gumbel_params = GumbelParams()
+        self.gumbel_params = asdict(gumbel_params) if is_dataclass(gumbel_params) else dict(gumbel_params)
+
+        assert not (use_ddp and num_codebooks > 1 and initialization_by_kmeans), (
+            "kmeans init is not compatible with multiple codebooks in distributed environment for now"
+        )
+
+        start = torch.zeros(num_codebooks, codebook_size, dim) if initialization_by_kmeans else _default_codebook(
+            num_codebooks, codebook_size, dim)
+        start = self.weights_regularization(start)
+        self.is_initialized = not initialization_by_kmeans
+        self.register_buffer("cluster_size", torch.zeros(num_codebooks, codebook_size))
+        self.register_buffer("embed_avg", start.clone())
+        if learnable_codebook:
+            self.embeddings = nn.Parameter(start)
+        else:
+            self.register_buffer("embeddings", start)
+
+    # ------------------------------------------------------------------ helpers
+    def _stochastic_requested(self) -> bool:
+        g = self.gumbel_params
+        return bool(self.training and g.get("stochastic", False) and g.get("temperature", 1.0) > 0)
+
+    def _sync_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.use_ddp and dist.is_available() and dist.is_initialized():
+            dist.all_reduce(t)
+        return t
+
+    def current_codes(self) -> torch.Tensor:
+        return self.embeddings if self.learnable_codebook else self.embeddings.detach()
+
+    # ------------------------------------------------------------------ the hot path
+    def quantize_flat(self, flat: torch.Tensor, *, ste: bool = False, want_sq_err: bool = False,
+                      codebook_grad_from_err: bool = False, out=None, idx=None):
+        """flat [h, M, D] (strided rows fine) -> (out [h, M, D], idx [h, M] int64, sq_err [1] float64 | None)."""
+        if self._stochastic_requested():
+            raise NotImplementedError("stochastic (Gumbel) code sampling is RNG-dependent and not part of the "
+                                      "native deterministic search (SURVEY 2, #4)")
+        codes = self.current_codes()
+        out, idx, sq_err = search.quantize_rows(flat, codes[:, None], metric=self.metric, ste=ste,
+                                                want_sq_err=want_sq_err,
+                                                codebook_grad_from_err=codebook_grad_from_err, out=out, idx=idx)
+        return out, idx[..., 0], sq_err
+
+    def similarities(self, flat: torch.Tensor) -> torch.Tensor:
+        """The [h, M, K] matrix the reference returns on every call (codebooks.py:386,435).  Only its rare
+        consumers need it (cross-entropy / diversity losses), so it is computed on demand with plain
+        PyTorch ops on the tensor's device instead of being produced by the search kernel."""
+        codes = self.current_codes()
+        if self.use_cosine_sim:
+            return torch.einsum("hnd,hcd->hnc", flat.float(), codes)
+        return -torch.cdist(flat.float(), codes)
+
+    def forward(self, x, mask=None, freeze_codebook=False, return_similarities=False):
+        """(quantize, embed_ind, similarities) like the reference; ``similarities`` is None unless asked for."""
+        squeeze_head = x.ndim < 4
+        x = x.float()
+        if squeeze_head:
+            x = x.unsqueeze(0)
+        h, d = x.shape[0], x.shape[-1]
+        lead = x.shape[1:-1]
+        flat = x.reshape(h, -1, d)
+        flat_mask = None
+        if mask is not None:
+            reps = flat.shape[1] // (mask.shape[0] * mask.shape[1])
+            flat_mask = mask[:, None, :].expand(mask.shape[0], reps, mask.shape[1]).reshape(1, -1).expand(h, -1)
+
+        if not self.is_initialized:
+            self.seed_with_kmeans(flat, flat_mask)
+            self.is_initialized = True
+
+        out, idx, _ = self.quantize_flat(flat)
+        sims = self.similarities(flat).reshape(h, *lead, self.codebook_size) if return_similarities else None
+
+        if self.training and self.ema_update and not freeze_codebook:
+            self.ema_step(flat.detach(), idx, flat_mask)
+
+        quantize = out.reshape(h, *lead, d)
+        embed_ind = idx.reshape(h, *lead)
+        if squeeze_head:
+            quantize, embed_ind = quantize[0], embed_ind[0]
+            if sims is not None:
+                sims = sims  # keeps the head dim, like the reference (codebooks.py:433)
+        return quantize, embed_ind, sims
+
+    # ------------------------------------------------------------------ training-state bookkeeping
+    @torch.no_grad()
+    def ema_step(self, flat: torch.Tensor, idx: torch.Tensor, flat_mask=None):
+        """Exponential-moving-average codebook update + dead-code re-seeding (codebooks.py:399-426),
+        expressed with index arithmetic instead of the reference's [h, M, K] one-hot products."""
+        h, m, d = flat.shape
+        k = self.codebook_size
+        weights = torch.ones((h, m), dtype=flat.dtype, device=flat.device)
+        if flat_mask is not None:
+            weights = weights * flat_mask.to(flat.dtype)
+        hits = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
+        hits.scatter_add_(1, idx, weights)
+        self._sync_sum(hits)
+        self.cluster_size.data.lerp_(hits, 1.0 - self.decay)
+
+        sums = torch.zeros((h, k, d), dtype=flat.dtype, device=flat.device)
+        sums.scatter_add_(1, idx[..., None].expand(h, m, d), flat * weights[..., None])
+        self._sync_sum(sums)
+        self.embed_avg.data.lerp_(sums, 1.0 - self.decay)
+
+        total = self.cluster_size.sum(dim=-1, keepdim=True)
+        smoothed = (self.cluster_size + self.eps_for_smoothing) / (total + k * self.eps_for_smoothing) * total
+        fresh = self.weights_regularization(self.embed_avg / smoothed[..., None])
+        self.embeddings.data.copy_(fresh)
+        self.reseed_dead_codes(flat)
+
+    @torch.no_grad()
+    def reseed_dead_codes(self, flat: torch.Tensor):
+        if self.threshold_ema_dead_code == 0:
+            return
+        dead = self.cluster_size < self.threshold_ema_dead_code
+        if not bool(dead.any()):
+            return
+        pool = self.weights_regularization(flat)
+        for head in range(pool.shape[0]):
+            n_dead = int(dead[head].sum().item())
+            if n_dead == 0:
+                continue
+            picked = _pick_rows(pool[head], n_dead)
+            self.embeddings.data[head][dead[head]] = picked
+            self.cluster_size.data[head][dead[head]] = self.reset_cluster_size
+            self.embed_avg.data[head][dead[head]] = picked * self.reset_cluster_size
+
+    @torch.no_grad()
+    def seed_with_kmeans(self, flat: torch.Tensor, flat_mask=None):
+        """Lloyd iterations on the first batch (utils/kmeans.py:38-120); the assignment step is the
+        native search kernel."""
+        if flat_mask is not None:
+            h = flat.shape[0]
+            flat = flat[flat_mask].reshape(h, -1, flat.shape[-1])
+        h, m, d = flat.shape
+        k = self.codebook_size
+        iters = (self.kmeans_params or {}).get("iter", 10)
+        sync = self.use_ddp and (self.kmeans_params or {}).get("sync", True)
+        data = _unit_rows(flat) if self.use_cosine_sim else flat
+        means = torch.stack([_pick_rows(data[i], k) for i in range(h)])
+        counts = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
+        for _ in range(iters):
+            idx, _best, _ = search.nearest_with_distance(data, means, metric=self.metric)
+            counts = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
+            counts.scatter_add_(1, idx, torch.ones((h, m), dtype=flat.dtype, device=flat.device))
+            sums = torch.zeros((h, k, d), dtype=flat.dtype, device=flat.device)
+            sums.scatter_add_(1, idx[..., None].expand(h, m, d), data)
+            if sync and dist.is_initialized():
+                dist.all_reduce(counts)
+                dist.all_reduce(sums)
+            fresh = sums / counts.clamp(min=1.0)[..., None]
+            if self.use_cosine_sim:
+                fresh = _unit_rows(fresh)
+            means = torch.where((counts == 0)[..., None], means, fresh)
+        self.embeddings.data.copy_(means)
+        self.embed_avg.data.copy_(means * counts[..., None])
+        self.cluster_size.data.copy_(counts)

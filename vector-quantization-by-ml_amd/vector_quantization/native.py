@@ -159,11 +159,14 @@ def _row_strides(t: torch.Tensor):
 
 def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bool = False, want_out: bool = True,
              want_sq_err: bool = False, want_best: bool = True, packed: torch.Tensor | None = None,
-             stages_share_codebook: bool = False, flags: int = 0, out: torch.Tensor | None = None):
+             stages_share_codebook: bool = False, flags: int = 0, out: torch.Tensor | None = None,
+             idx: torch.Tensor | None = None):
     """The hot path through the C ABI.
 
     x   [H, M, D] fp32 (rows may be strided, last dim contiguous)
-    cb  [H, Q, K, D] fp32 contiguous natural codebooks ([H, 1, K, D] with stages_share_codebook)
+    cb  [H, Q, K, D] fp32 contiguous natural codebooks ([H, 1, K, D] with stages_share_codebook; Q stages
+        are then given by ``idx.shape[-1]`` or default to 1)
+    out [H, M, D] optional destination VIEW (any row / head strides), idx [H, M, Q] optional int64 VIEW
     returns dict(out [H, M, D] | None, idx [H, M, Q] int64, best [H, M, Q] | None, sq_err [Q] float64 | None)
     """
     _require_gpu(x, cb)
@@ -172,17 +175,27 @@ def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bo
     H, M, D = x.shape
     Hc, Qc, K, Dc = cb.shape
     assert Hc == H and Dc == D
-    Q = Qc
+    if stages_share_codebook:
+        assert Qc == 1
+        Q = idx.shape[-1] if idx is not None else 1
+    else:
+        Q = Qc
     dev = x.device
     if packed is None:
         packed = pack_codebooks(cb, metric)
     pf = packed.shape[-1]
     x_rs, x_hs = _row_strides(x)
-    idx = torch.empty((H, M, Q), dtype=torch.int64, device=dev)
-    best = torch.empty((H, M, Q), dtype=torch.float32, device=dev) if want_best else None
+    if idx is None:
+        idx = torch.empty((H, M, Q), dtype=torch.int64, device=dev)
+    assert idx.dtype == torch.int64 and tuple(idx.shape) == (H, M, Q)
+    best = None
+    if want_best:
+        best = torch.empty_strided((H, M, Q), idx.stride(), dtype=torch.float32, device=dev) if M > 0 else \
+            torch.empty((H, M, Q), dtype=torch.float32, device=dev)
     if want_out:
         if out is None:
             out = torch.empty((H, M, D), dtype=torch.float32, device=dev)
+        assert out.dtype == torch.float32 and tuple(out.shape) == (H, M, D)
         o_rs, o_hs = _row_strides(out)
     else:
         out, o_rs, o_hs = None, 0, 0
@@ -195,7 +208,7 @@ def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bo
     a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), Qc * K * D, (0 if stages_share_codebook else K * D)
     a.packed, a.pk_hs, a.pk_qs = packed.data_ptr(), Qc * pf, (0 if stages_share_codebook else pf)
     a.out, a.out_rs, a.out_hs = (out.data_ptr() if out is not None else None), o_rs, o_hs
-    a.idx, a.idx_rs, a.idx_hs, a.idx_qs = idx.data_ptr(), Q, M * Q, 1
+    a.idx, a.idx_hs, a.idx_rs, a.idx_qs = idx.data_ptr(), int(idx.stride(0)), int(idx.stride(1)), int(idx.stride(2))
     a.best = best.data_ptr() if best is not None else None
     a.sq_err = sq_err.data_ptr() if sq_err is not None else None
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8

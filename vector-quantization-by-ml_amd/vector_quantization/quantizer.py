@@ -1,0 +1,242 @@
+"""``VectorQuantize``: public nn.Module of the drop-in (reference:
+/root/reference/vector_quantization/vector_quantize_pytorch.py:38-430).
+
+Same constructor / ``forward`` signature, sub-module names (``_codebook``, ``project_in``, ``project_out``)
+and return convention ``(quantize, embed_ind, loss)``.  The body is organised differently from the
+reference: every input layout is reduced to a *strided view* ``[heads, rows, dim]`` of one buffer, the
+whole quantize step -- search, gather, straight-through output, squared error for the commitment
+loss -- is ONE native call on that view (no head transposes, no ``[rows, K]`` intermediates), and the
+results are viewed back.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from dataclasses import asdict, replace
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .codebook import Codebook
+from .params import CodebookParams
+
+LossBreakdown = namedtuple(
+    "LossBreakdown", ["commitment", "codebook_diversity", "orthogonal_reg", "inplace_optimize"]
+)
+
+
+def _world_is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class VectorQuantize(nn.Module):
+    def __init__(
+        self,
+        dim,
+        codebook_params: CodebookParams,
+        codebook_dim=None,
+        heads=1,
+        separate_codebook_per_head=False,
+        layernorm_after_project_in=False,
+        channel_last=True,
+        commitment_weight=1.0,
+        commitment_use_cross_entropy_loss=False,
+        orthogonal_reg_weight=0.0,
+        orthogonal_reg_active_codes_only=False,
+        orthogonal_reg_max_codes=None,
+        codebook_diversity_loss_weight=0.0,
+        codebook_diversity_temperature=100.0,
+        sync_codebook=None,
+        in_place_codebook_optimizer: Optional[Callable] = None,
+        sync_update_v=0.0,
+    ):
+        super().__init__()
+        self.dim = dim
+        self.heads = heads
+        self.separate_codebook_per_head = separate_codebook_per_head
+        self.channel_last = channel_last
+
+        head_dim = dim if codebook_dim is None else codebook_dim
+        inner = head_dim * heads
+        self.has_projections = inner != dim
+        if self.has_projections:
+            lin = nn.Linear(dim, inner)
+            self.project_in = nn.Sequential(lin, nn.LayerNorm(inner)) if layernorm_after_project_in else lin
+            self.project_out = nn.Linear(inner, dim)
+        else:
+            self.project_in = nn.Identity()
+            self.project_out = nn.Identity()
+
+        self.commitment_weight = commitment_weight
+        self.has_commitment_loss = commitment_weight > 0.0
+        self.commitment_use_cross_entropy_loss = commitment_use_cross_entropy_loss
+        self.has_codebook_orthogonal_loss = orthogonal_reg_weight > 0.0
+        self.orthogonal_reg_weight = orthogonal_reg_weight
+        self.orthogonal_reg_active_codes_only = orthogonal_reg_active_codes_only
+        self.orthogonal_reg_max_codes = orthogonal_reg_max_codes
+        self.has_codebook_diversity_loss = codebook_diversity_loss_weight > 0.0
+        self.codebook_diversity_loss_weight = codebook_diversity_loss_weight
+        self.codebook_diversity_temperature = codebook_diversity_temperature
+
+        assert not (codebook_params.ema_update and codebook_params.learnable_codebook), (
+            "learnable codebook not compatible with EMA update"
+        )
+        assert 0 <= sync_update_v <= 1.0
+        assert not (sync_update_v > 0.0 and not codebook_params.learnable_codebook), (
+            "learnable codebook must be turned on"
+        )
+        self.sync_update_v = sync_update_v
+        if sync_update_v > 0.0:
+            raise NotImplementedError("synchronous update rule (sync_update_v) is outside the hot-path build")
+        if in_place_codebook_optimizer is not None:
+            raise NotImplementedError("in_place_codebook_optimizer is outside the hot-path build")
+        if self.has_codebook_orthogonal_loss or self.has_codebook_diversity_loss or commitment_use_cross_entropy_loss:
+            raise NotImplementedError(
+                "orthogonal / diversity / cross-entropy losses consume the full similarity matrix and are outside "
+                "the MI355X hot-path build (SURVEY 8f rank 3); only the MSE commitment loss is native"
+            )
+        self.in_place_codebook_optimizer = None
+
+        if sync_codebook is None:
+            sync_codebook = _world_is_distributed()
+        self.codebook_params = replace(
+            codebook_params,
+            dim=head_dim,
+            num_codebooks=heads if separate_codebook_per_head else 1,
+            learnable_codebook=self.has_codebook_orthogonal_loss or codebook_params.learnable_codebook,
+            use_ddp=sync_codebook,
+        )
+        self.learnable_codebook = codebook_params.learnable_codebook
+        self._codebook = Codebook(**asdict(self.codebook_params))
+        self.register_buffer("zero", torch.tensor(0.0), persistent=False)
+
+    # ------------------------------------------------------------------ codebook access (repaired w.r.t. the fork)
+    @property
+    def codebook(self):
+        """[K, D] (or [heads, K, D] with per-head codebooks).  The fork reads a non-existent ``.embed``
+        (vector_quantize_pytorch.py:142); this build exposes the real buffer."""
+        codes = self._codebook.embeddings
+        return codes if self.separate_codebook_per_head else codes[0]
+
+    @codebook.setter
+    def codebook(self, codes):
+        if not self.separate_codebook_per_head:
+            codes = codes[None]
+        with torch.no_grad():
+            self._codebook.embeddings.copy_(codes)
+
+    def get_codes_from_indices(self, indices):
+        codes = self.codebook
+        if codes.ndim == 2:
+            out = codes[indices]
+        else:  # indices [b, ..., h] -> concatenate the per-head codes on the feature axis
+            per_head = [codes[h][indices[..., h]] for h in range(codes.shape[0])]
+            out = torch.cat(per_head, dim=-1)
+        if not self.channel_last:
+            out = out.movedim(-1, 1)
+        return out
+
+    def get_output_from_indices(self, indices):
+        codes = self.get_codes_from_indices(indices)
+        if not self.channel_last:
+            return self.project_out(codes.movedim(1, -1)).movedim(-1, 1)
+        return self.project_out(codes)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, indices=None, mask=None, freeze_codebook=False, return_loss_breakdown=False):
+        if indices is not None:
+            raise NotImplementedError("cross-entropy to given indices needs the similarity matrix (SURVEY 8f rank 3)")
+        orig_input = x
+        single_vectors = x.ndim == 2
+        if single_vectors:
+            assert mask is None
+            x = x[:, None, :]
+
+        if not self.channel_last:
+            x = x.movedim(1, -1)  # b d ... -> b ... d (view)
+        spatial = tuple(x.shape[1:-1])
+        batch = x.shape[0]
+        x = x.reshape(batch, -1, x.shape[-1])  # b n d  (copy only if the permuted view cannot be flattened)
+        n = x.shape[1]
+        x = self.project_in(x)
+
+        heads, cb = self.heads, self._codebook
+        head_dim = x.shape[-1] // heads
+        x4 = x.reshape(batch, n, heads, head_dim)
+        x4 = cb.transform_input(x4)
+        if x4.dtype != torch.float32:
+            x4 = x4.float()
+        if not x4.is_contiguous():
+            x4 = x4.contiguous()
+        rows = batch * n
+        # destination buffers in (row, head) order; the kernel writes through strided views of them
+        q_buf = torch.empty((rows, heads, head_dim), dtype=torch.float32, device=x4.device)
+        i_buf = torch.empty((rows, heads, 1), dtype=torch.int64, device=x4.device)
+        if self.separate_codebook_per_head:
+            flat = x4.view(rows, heads, head_dim).permute(1, 0, 2)  # [h, rows, d] strided view, no copy
+            out_view, idx_view = q_buf.permute(1, 0, 2), i_buf.permute(1, 0, 2)
+        else:
+            flat = x4.view(1, rows * heads, head_dim)  # one codebook: heads are just more rows
+            out_view, idx_view = q_buf.view(1, rows * heads, head_dim), i_buf.view(1, rows * heads, 1)
+
+        training = self.training
+        want_loss = training and self.has_commitment_loss
+        flat_mask = None
+        if mask is not None:
+            per_row = mask.reshape(rows)
+            flat_mask = (per_row[None, :].expand(heads, rows) if self.separate_codebook_per_head
+                         else per_row[:, None].expand(rows, heads).reshape(1, rows * heads))
+
+        if not cb.is_initialized:
+            cb.seed_with_kmeans(flat.detach(), flat_mask)
+            cb.is_initialized = True
+
+        loss = torch.zeros(1, device=x.device, dtype=torch.float32)
+        commit_loss = self.zero
+        cb_grad_from_err = self.learnable_codebook and not freeze_codebook
+        if mask is None:
+            # the one native launch: search + gather + straight-through + squared error
+            out, idx, sq_err = cb.quantize_flat(flat, ste=training, want_sq_err=want_loss,
+                                                codebook_grad_from_err=cb_grad_from_err, out=out_view, idx=idx_view)
+            if want_loss:
+                commit_loss = (sq_err[0] / flat.numel()).to(torch.float32)
+        else:
+            out, idx, _ = cb.quantize_flat(flat.detach() if not cb_grad_from_err else flat, ste=False, idx=idx_view)
+            if want_loss:
+                target = out if cb_grad_from_err else out.detach()
+                commit_loss = ((target - flat) ** 2)[flat_mask].mean()
+            if training:
+                out = flat + (out - flat).detach()
+        if want_loss:
+            loss = loss + commit_loss * self.commitment_weight
+
+        if training and cb.ema_update and not freeze_codebook:
+            cb.ema_step(flat.detach(), idx, flat_mask)
+
+        # ---- view the results back: rows are (b, n[, h]) ordered in both head modes
+        if self.separate_codebook_per_head:
+            quantize = out.permute(1, 0, 2).reshape(batch, n, heads * head_dim)  # a view when `out` is q_buf's
+        else:
+            quantize = out.reshape(batch, n, heads * head_dim)
+        embed_ind = i_buf.view(batch, n, heads)
+        if heads == 1:
+            embed_ind = embed_ind[..., 0]
+            embed_ind = embed_ind.reshape(batch, *spatial)
+        else:
+            embed_ind = embed_ind.reshape(batch, *spatial, heads)
+        if single_vectors:
+            embed_ind = embed_ind[:, 0]
+
+        quantize = self.project_out(quantize)
+        quantize = quantize.reshape(batch, *spatial, quantize.shape[-1])
+        if not self.channel_last:
+            quantize = quantize.movedim(-1, 1)
+        if single_vectors:
+            quantize = quantize[:, 0]
+        if mask is not None:
+            quantize = torch.where(mask[..., None], quantize, orig_input)
+
+        if not return_loss_breakdown:
+            return quantize, embed_ind, loss
+        return quantize, embed_ind, loss, LossBreakdown(commit_loss, self.zero, self.zero, self.zero)

@@ -1,0 +1,124 @@
+"""Functional seam between the nn.Modules and the native op.
+
+``quantize_rows`` is the ONE call every module makes for the hot path.  It dispatches to
+``native.quantize`` (HIP kernels through the C ABI).  There is no CPU implementation in this package;
+tests may install a checker backend with ``set_backend`` (tests/ only) to exercise the host-side
+layout logic on a machine without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import native
+
+EUCLID = native.EUCLID
+DOT = native.DOT
+
+
+class _NativeBackend:
+    name = "hip-gfx950"
+
+    @staticmethod
+    def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None):
+        r = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, want_best=want_best,
+                            stages_share_codebook=share, out=out, idx=idx)
+        return r["out"], r["idx"], r["best"], r["sq_err"]
+
+
+_backend = _NativeBackend
+
+
+def set_backend(backend) -> None:
+    """Install a different backend object exposing ``quantize`` (used by the CPU-only host-logic tests)."""
+    global _backend
+    _backend = backend if backend is not None else _NativeBackend
+
+
+def get_backend():
+    return _backend
+
+
+class _QuantizeFn(torch.autograd.Function):
+    """Autograd wrapper.  The native op has no backward of its own; the gradients are the reference's:
+
+    * train (ste): out_q = r_q + (c_q - r_q).detach()  -> d out / d x = Q * I   (residual_vq.py:232-233,
+      vector_quantize_pytorch.py:273: every stage's residual is x minus detached terms)
+    * sq_err_q = sum (c_q.detach() - r_q)^2              -> d / d x = 2 (r_q - c_q)
+    * a learnable codebook receives  2 (c_q - r_q)  from sq_err when ``codebook_grad_from_err``
+      (commitment loss not detached, vector_quantize_pytorch.py:263-269) and, in eval, the scatter of
+      grad_out (out = codebook[idx]).
+    """
+
+    @staticmethod
+    def forward(ctx, x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out_buf, idx_buf):
+        out, idx, _best, sq_err = _backend.quantize(x.detach(), cb.detach(), metric=metric, ste=ste,
+                                                    want_sq_err=want_sq_err, share=share, out=out_buf, idx=idx_buf)
+        ctx.save_for_backward(x, cb, idx)
+        ctx.ste, ctx.share, ctx.cb_err = ste, share, codebook_grad_from_err
+        ctx.mark_non_differentiable(idx)
+        if sq_err is None:
+            sq_err = torch.zeros(idx.shape[-1], dtype=torch.float64, device=x.device)
+        return out, idx, sq_err
+
+    @staticmethod
+    def backward(ctx, g_out, _g_idx, g_err):
+        x, cb, idx = ctx.saved_tensors
+        H, M, D = x.shape
+        Q = idx.shape[-1]
+        gx = gcb = None
+        need_x = ctx.needs_input_grad[0]
+        need_cb = ctx.needs_input_grad[1]
+        if need_x:
+            gx = g_out * float(Q) if ctx.ste else torch.zeros_like(x)
+        if need_cb:
+            gcb = torch.zeros_like(cb)
+        has_err = g_err is not None and bool((g_err != 0).any())
+        if (need_x and has_err) or need_cb:
+            r = x.detach()
+            harange = torch.arange(H, device=x.device)[:, None]
+            for q in range(Q):
+                cq = cb[:, 0 if ctx.share else q].detach()  # [H, K, D]
+                i = idx[..., q]
+                c = cq[harange, i]  # [H, M, D]
+                if has_err:
+                    w = g_err[q].to(x.dtype)
+                    if need_x:
+                        gx = gx + 2.0 * w * (r - c)
+                    if need_cb and ctx.cb_err:
+                        gcb[:, 0 if ctx.share else q].index_put_((harange.expand_as(i), i), 2.0 * w * (c - r),
+                                                                 accumulate=True)
+                if need_cb and not ctx.ste and g_out is not None:
+                    gcb[:, 0 if ctx.share else q].index_put_((harange.expand_as(i), i), g_out, accumulate=True)
+                quant = r + (c - r) if ctx.ste else c
+                r = r - quant
+        return gx, gcb, None, None, None, None, None, None, None
+
+
+def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bool = False,
+                  want_sq_err: bool = False, share: bool = False, codebook_grad_from_err: bool = False,
+                  out: Optional[torch.Tensor] = None, idx: Optional[torch.Tensor] = None):
+    """x [H, M, D] (strided rows allowed), cb [H, Q, K, D] contiguous ([H, 1, K, D] when ``share``; the number
+    of stages is then ``idx.shape[-1]``).  ``out`` / ``idx`` may be pre-allocated (strided) destination views.
+
+    Returns (out [H, M, D], idx [H, M, Q] int64, sq_err [Q] float64 or None).
+    """
+    if x.dtype != torch.float32:
+        x = x.float()
+    if not cb.is_contiguous():
+        cb = cb.contiguous()
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or cb.requires_grad)
+    if needs_grad:
+        out, idx, sq_err = _QuantizeFn.apply(x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out, idx)
+        return out, idx, (sq_err if want_sq_err else None)
+    out, idx, _best, sq_err = _backend.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, share=share,
+                                                out=out, idx=idx)
+    return out, idx, sq_err
+
+
+def nearest_with_distance(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID):
+    """Search only: (idx [H, M], best [H, M]) -- used by k-means seeding and diagnostics."""
+    out, idx, best, _ = _backend.quantize(x.float(), cb[:, None].contiguous(), metric=metric, ste=False,
+                                          want_sq_err=False, share=False, want_best=True)
+    return idx[..., 0], best[..., 0], out

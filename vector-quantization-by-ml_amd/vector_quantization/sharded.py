@@ -1,0 +1,93 @@
+"""Codebook-sharded nearest search over one node's GPUs (new capability; not in the reference).
+
+Rank g of the process group holds rows ``[g*K/G, (g+1)*K/G)`` of a codebook that is searched as a whole:
+
+    1. every rank searches ITS shard for all rows (native kernel) and emits one packed signed 64-bit key per
+       row: (order image of the winning value) << 32 | (global code index);
+    2. ONE collective: ``all_reduce(keys, op=MIN)`` (RCCL ``ncclMin`` on int64 over xGMI; 8 bytes per row).
+       Equal distances resolve to the lowest GLOBAL index -- the reference's first-argmax semantics
+       (utils/general.py:128) -- because the index sits in the low word;
+    3. finalize: decode, gather ``codebook[idx]``.  The gather table is either a replicated full copy
+       (``gather="replicated"``: 128 MiB at K=65536, D=512 is nothing in 288 GB) or stays sharded
+       (``gather="owner"``: the owner rank contributes the row, everybody else zeros, and a SUM all-reduce
+       delivers it: x + 0 is exact).
+
+Parity target: the single-process reference with the full codebook.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import native
+
+KEY_INIT = 0x7FFFFFFFFFFFFFFF
+
+
+class _NativeShardOps:
+    """The three device steps, through the C ABI."""
+
+    @staticmethod
+    def local_keys(x, shard, metric, idx_offset):
+        keys = torch.empty((1, x.shape[0]), dtype=torch.int64, device=x.device)
+        native.keys_init(keys)
+        native.search_keys(x[None], shard[None].contiguous(), keys, metric=metric, idx_offset=idx_offset)
+        return keys[0]
+
+    @staticmethod
+    def finalize(x, table, keys, metric, ste, want_sq_err):
+        r = native.finalize_keys(x[None], table[None].contiguous(), keys[None].contiguous(), metric=metric, ste=ste,
+                                 want_sq_err=want_sq_err)
+        return r["out"][0], r["idx"][0], r["best"][0], (r["sq_err"] if want_sq_err else None)
+
+    @staticmethod
+    def decode(keys, metric):
+        idx = keys & 0xFFFFFFFF
+        return idx
+
+
+class ShardedCodebookSearch:
+    """Nearest-code search against a codebook sharded over the ranks of ``group``.
+
+    ``shard`` is this rank's [K/G, D] slice (rank order = index order).  ``full_codebook`` (optional) is a
+    replicated [K, D] copy used only for the final gather.
+    """
+
+    def __init__(self, shard: torch.Tensor, *, use_cosine_sim: bool = False, group=None,
+                 full_codebook: Optional[torch.Tensor] = None, ops=None):
+        self.group = group
+        self.metric = native.DOT if use_cosine_sim else native.EUCLID
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.shard = shard.contiguous().float()
+        self.k_local = shard.shape[0]
+        self.k_total = self.k_local * self.world
+        self.full = full_codebook
+        self.ops = ops if ops is not None else _NativeShardOps
+
+    def search_keys(self, x: torch.Tensor) -> torch.Tensor:
+        """x [M, D] (identical on every rank) -> reduced keys [M] int64 (identical on every rank)."""
+        keys = self.ops.local_keys(x.float(), self.shard, self.metric, self.rank * self.k_local)
+        if self.world > 1:
+            dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
+        return keys
+
+    def __call__(self, x: torch.Tensor, *, ste: bool = False, want_sq_err: bool = False):
+        """-> (quantized [M, D], idx [M] int64 GLOBAL indices, best [M], sq_err | None)."""
+        x = x.float()
+        keys = self.search_keys(x)
+        if self.full is not None or self.world == 1:
+            table = self.full if self.full is not None else self.shard
+            return self.ops.finalize(x, table, keys, self.metric, ste, want_sq_err)
+        # owner-contributes gather: rows whose winner lives elsewhere are zero here
+        idx = keys & 0xFFFFFFFF
+        local = idx - self.rank * self.k_local
+        mine = (local >= 0) & (local < self.k_local)
+        q = torch.zeros((x.shape[0], self.shard.shape[1]), dtype=torch.float32, device=x.device)
+        q[mine] = self.shard[local[mine]]
+        dist.all_reduce(q, op=dist.ReduceOp.SUM, group=self.group)
+        sq_err = ((q - x).double() ** 2).sum().reshape(1) if want_sq_err else None
+        out = x + (q - x) if ste else q
+        return out, idx, None, sq_err
