@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/vq_mi355x.h"
@@ -145,7 +146,10 @@ struct SearchParams {
     int vec_fin;  // finalize may use float4 on x / out / cb
 };
 
-__device__ __forceinline__ void glds16(const float *g, f32x4 *l) {
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
+// LDS-DMA: 16 B per lane, LDS destination = wave-uniform base + lane * 16 (no VGPR round trip)
+__device__ __forceinline__ void glds16(const float *g, lds_f32x4 *l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
@@ -160,19 +164,121 @@ struct Geo {
     static constexpr int CH = DP < 64 ? DP : 64;            // prologue column chunk
     static constexpr int XS = CH + 1;                       // prologue scratch row stride, floats (odd)
     static constexpr int NS = DP / 2;                       // MFMA k-steps
-    static constexpr int MAIN_FLOATS = (2 * BUF_F4 * 4 > WAVES * 32 * XS) ? 2 * BUF_F4 * 4 : WAVES * 32 * XS;
+    static constexpr int NBUF = 2;
+    static constexpr int MAIN_FLOATS = (NBUF * BUF_F4 * 4 > WAVES * 32 * XS) ? NBUF * BUF_F4 * 4 : WAVES * 32 * XS;
     static constexpr int NCH4 = DP >= 256 ? DP / 256 : 1;   // float4 chunks per lane in finalize
     static constexpr int NEL = DP >= 64 ? DP / 64 : 1;      // scalars per lane in finalize
 };
 
+// code fragments: one ds_read_b128 feeds 4 MFMAs (256 cycles of matrix pipe); keep PF reads in flight and pin the
+// order so the scheduler cannot hoist every read to the top (register pressure).  `hook(g)` is expanded after
+// MFMA group g: VALU / LDS-DMA work placed there issues while the group's MFMAs occupy the matrix pipe.
+template <int DP, typename Hook>
+__device__ __forceinline__ void mfma_tile(f32x16 &acc, const f32x4 *ta, const float (&xf)[DP / 2], Hook hook) {
+    constexpr int NG = DP / 8;
+    constexpr int PF = NG < 3 ? NG : 3;
+    f32x4 a[NG];
+#pragma unroll
+    for (int g = 0; g < PF; ++g) a[g] = ta[2 * g];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + PF < NG) a[g + PF] = ta[2 * (g + PF)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, xf[4 * g + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, xf[4 * g + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, xf[4 * g + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, xf[4 * g + 3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        hook(g);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// End of a 32-code tile for one wave: augmented-column MFMA (Euclid), tail masking, in-lane reduction.
+// A lane holds 16 codes of ONE row: acc[r] <-> code t*32 + 4*h + (r&3) + 8*(r>>2), ascending in r.
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float o;  // raw instruction: no canonicalising v_max in front (MFMA outputs are already canonical)
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float o;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+
+template <int METRIC, int DP>
+__device__ __forceinline__ void tile_epilogue(f32x16 &acc, int t, int h, int K, float &best_t, float &best_s,
+                                              int &best_i) {
+    const float INF = __builtin_inff();
+    const int cbase = t * kTileCodes + 4 * h;
+    if (METRIC == VQ_METRIC_EUCLID) {
+        if (t * kTileCodes + kTileCodes > K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (cbase + (r & 3) + 8 * (r >> 2) >= K) acc[r] = INF;
+        }
+        float tm = vmin3(acc[0], acc[1], acc[2]);
+        tm = vmin3(tm, acc[3], acc[4]);
+        tm = vmin3(tm, acc[5], acc[6]);
+        tm = vmin3(tm, acc[7], acc[8]);
+        tm = vmin3(tm, acc[9], acc[10]);
+        tm = vmin3(tm, acc[11], acc[12]);
+        tm = vmin3(tm, acc[13], acc[14]);
+        tm = vmax3(fminf(tm, acc[15]), 0.0f, 0.0f);  // clamp_min_(0) commutes with min
+        if (tm < best_t) {
+            // A new record low of the (clamped) squared distance: only now can the argmin change.
+            // Closed form of the in-order scan: s = sqrt(tile min); if it beats the running best, the winner is
+            // the LOWEST code of this lane whose sqrt rounds to the same s, i.e. whose t < (s + ulp(s)/2)^2.  That
+            // bound is exact in fp64 (square of a 25-bit value); `hi` is the largest fp32 below it, so the per-code
+            // test is one fp32 compare on the UNclamped value (t < 0 clamps to 0 <= hi anyway).
+            best_t = tm;
+            const float sq = sqrtf(tm);  // correctly rounded
+            if (sq < best_s) {
+                best_s = sq;
+                const float up = __uint_as_float(__float_as_uint(sq) + 1u);  // next float above (sq >= 0)
+                const double mid = (double)sq + 0.5 * ((double)up - (double)sq);
+                const double lim = mid * mid;
+                float hi = (float)lim;
+                if ((double)hi >= lim) hi = __uint_as_float(__float_as_uint(hi) - 1u);  // lim > 0 always
+                int bi = 0;
+#pragma unroll
+                for (int r = 15; r >= 0; --r) bi = (acc[r] <= hi) ? (r & 3) + 8 * (r >> 2) : bi;
+                best_i = cbase + bi;
+            }
+        }
+    } else {
+        if (t * kTileCodes + kTileCodes > K) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (cbase + (r & 3) + 8 * (r >> 2) >= K) acc[r] = -INF;
+        }
+        float tm = vmax3(acc[0], acc[1], acc[2]);
+        tm = vmax3(tm, acc[3], acc[4]);
+        tm = vmax3(tm, acc[5], acc[6]);
+        tm = vmax3(tm, acc[7], acc[8]);
+        tm = vmax3(tm, acc[9], acc[10]);
+        tm = vmax3(tm, acc[11], acc[12]);
+        tm = vmax3(tm, acc[13], acc[14]);
+        tm = vmax3(tm, acc[15], acc[15]);
+        if (tm > best_s) {  // strictly better than everything earlier: take the lowest code that attains it
+            best_s = tm;
+            int bi = 0;
+#pragma unroll
+            for (int r = 15; r >= 0; --r) bi = (acc[r] == tm) ? (r & 3) + 8 * (r >> 2) : bi;
+            best_i = cbase + bi;
+        }
+    }
+}
+
 template <int DP, int WAVES, int METRIC, bool MULTI>
-__global__ void __launch_bounds__(WAVES * 64) vq_search_mfma(const SearchParams p) {
+__global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfma(const SearchParams p) {
     using G = Geo<DP, WAVES>;
     constexpr int RS = G::RS, RS4 = G::RS4, CH = G::CH, XS = G::XS, NS = G::NS;
     constexpr bool EUCLID = (METRIC == VQ_METRIC_EUCLID);
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4 *tile4 = (f32x4 *)smem;
+    lds_f32x4 *tile4_lds = (lds_f32x4 *)smem;  // same bytes, LDS address space (LDS-DMA destinations)
     int *sidx = (int *)(smem + G::MAIN_FLOATS);  // [WAVES][Q][32]
 
     const int tid = threadIdx.x;
@@ -250,94 +356,55 @@ __global__ void __launch_bounds__(WAVES * 64) vq_search_mfma(const SearchParams 
         const int t0 = blockIdx.z * p.tiles_per_split;
         const int t1 = (t0 + p.tiles_per_split < p.ntiles) ? t0 + p.tiles_per_split : p.ntiles;
 
-        // stage the first tile
+        auto stage = [&](int tile, int buf) {
 #pragma unroll
-        for (int i = 0; i < (G::TILE_CHUNKS + WAVES - 1) / WAVES; ++i) {
-            const int ck = i * WAVES + wave;
-            if (ck < G::TILE_CHUNKS) glds16(pk + ((long long)t0 * G::TILE_F4 + ck * 64 + lane) * 4, tile4 + ck * 64);
-        }
-        __syncthreads();
-
-        for (int t = t0; t < t1; ++t) {
+            for (int i = 0; i < (G::TILE_CHUNKS + WAVES - 1) / WAVES; ++i) {
+                const int ck = i * WAVES + wave;
+                if (ck < G::TILE_CHUNKS)
+                    glds16(pk + ((long long)tile * G::TILE_F4 + ck * 64 + lane) * 4,
+                           tile4_lds + buf * G::BUF_F4 + ck * 64);
+            }
+        };
+        // One tile: Dp/2 MFMAs into `acc`, then the augmented-column MFMA (|x|^2 * 1 + 1 * |c|^2).  Software
+        // pipelined inside the wave: the PREVIOUS tile's reduction (`prev`, finished long ago, so no MFMA drain)
+        // and the NEXT tile's LDS-DMA issue are expanded between MFMA groups, where they issue while the matrix
+        // pipe is busy with this tile.
+        auto run_tile = [&](f32x16 &acc, f32x16 &prev, int t, bool have_prev) {
             const int cur = (t - t0) & 1;
-            if (t + 1 < t1) {
-                f32x4 *nb = tile4 + (cur ^ 1) * G::BUF_F4;
-#pragma unroll
-                for (int i = 0; i < (G::TILE_CHUNKS + WAVES - 1) / WAVES; ++i) {
-                    const int ck = i * WAVES + wave;
-                    if (ck < G::TILE_CHUNKS)
-                        glds16(pk + ((long long)(t + 1) * G::TILE_F4 + ck * 64 + lane) * 4, nb + ck * 64);
-                }
-            }
             const f32x4 *tb = tile4 + cur * G::BUF_F4;
-            f32x16 acc = {0};
-            {
-                // code fragments: one ds_read_b128 feeds 4 MFMAs (256 cycles); keep PF reads in flight and
-                // pin the order so the scheduler cannot hoist every read to the top (register pressure).
-                constexpr int NG = DP / 8;
-                constexpr int PF = NG < 3 ? NG : 3;
-                const f32x4 *ta = tb + c * RS4 + h;
-                f32x4 a[NG];
-#pragma unroll
-                for (int g = 0; g < PF; ++g) a[g] = ta[2 * g];
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g + PF < NG) a[g + PF] = ta[2 * (g + PF)];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, xf[4 * g + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, xf[4 * g + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, xf[4 * g + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, xf[4 * g + 3], acc, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+            acc = (f32x16){0};
+            mfma_tile<DP>(acc, tb + c * RS4 + h, xf, [&](int g) {
+                if (g == 0) {
+                    if (have_prev) tile_epilogue<METRIC, DP>(prev, t - 1, h, p.K, best_t, best_s, best_i);
+                } else if (g == (DP >= 32 ? 2 : 1)) {
+                    if (t + 1 < t1) stage(t + 1, cur ^ 1);
                 }
-            }
-            const int cbase = t * kTileCodes + 4 * h;  // code of acc[r] = cbase + (r&3) + 8*(r>>2)
+            });
             if (EUCLID) {
                 const float cnv = ((const float *)tb)[c * RS + DP];
                 const float a_aug = h ? cnv : 1.0f;  // A[code][k=0] = 1, A[code][k=1] = |c|^2
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, acc, 0, 0, 0);
-                if (t * kTileCodes + kTileCodes > p.K) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (cbase + (r & 3) + 8 * (r >> 2) >= p.K) acc[r] = INF;
-                }
-                float tm = acc[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) tm = fminf(tm, acc[r]);
-                tm = fmaxf(tm, 0.0f);
-                if (tm < best_t) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float tv = fmaxf(acc[r], 0.0f);  // clamp_min_(0)
-                        if (tv < best_t) {                     // only a new record low can change the argmin
-                            const float s = sqrtf(tv);
-                            if (s < best_s) {                  // strict: equal sqrt keeps the earlier (lower) code
-                                best_s = s;
-                                best_i = cbase + (r & 3) + 8 * (r >> 2);
-                            }
-                            best_t = tv;
-                        }
-                    }
-                }
-            } else {
-                if (t * kTileCodes + kTileCodes > p.K) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (cbase + (r & 3) + 8 * (r >> 2) >= p.K) acc[r] = -INF;
-                }
-                float tm = acc[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, acc[r]);
-                if (tm > best_s) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (acc[r] > best_s) {
-                            best_s = acc[r];
-                            best_i = cbase + (r & 3) + 8 * (r >> 2);
-                        }
-                    }
-                }
             }
-            __syncthreads();  // next tile landed (vmcnt(0)) and everybody is done with this one
+            __syncthreads();  // next tile landed (vmcnt(0)) and everybody is done reading this one
+        };
+
+        stage(t0, 0);
+        __syncthreads();
+        {
+            f32x16 acc0, acc1;
+            int t = t0;
+            bool have_prev = false;
+            for (; t + 1 < t1; t += 2) {
+                run_tile(acc0, acc1, t, have_prev);
+                run_tile(acc1, acc0, t + 1, true);
+                have_prev = true;
+            }
+            if (t < t1) {
+                run_tile(acc0, acc1, t, have_prev);
+                tile_epilogue<METRIC, DP>(acc0, t, h, p.K, best_t, best_s, best_i);
+            } else if (have_prev) {
+                tile_epilogue<METRIC, DP>(acc1, t - 1, h, p.K, best_t, best_s, best_i);
+            }
         }
 
         // merge the two lane halves of each row (they saw disjoint codes)
@@ -923,6 +990,9 @@ int vq_quantize_f32(const vq_args *a, void *stream) {
     // ---- choose fused (one launch, no K split) or split (keys + finalize) ----
     bool fused = !simple;
     int waves = (DP == 512) ? 4 : 8;
+    if (const char *ev = getenv("VQ_WAVES")) {
+        if (atoi(ev) == 4) waves = 4;
+    }
     if (fused) {
         long long wgs = (long long)a->H * ((a->M + 32 * waves - 1) / (32 * waves));
         if (waves == 8 && wgs < cus) {
