@@ -162,7 +162,7 @@ struct Geo {
     static constexpr int TILE_CHUNKS = (TILE_F4 + 63) / 64; // 1-KiB wave copies per tile (over-copy)
     static constexpr int BUF_F4 = TILE_CHUNKS * 64;
     static constexpr int CH = DP < 64 ? DP : 64;            // prologue column chunk
-    static constexpr int XS = CH + 1;                       // prologue scratch row stride, floats (odd)
+    static constexpr int XS = CH + 4;                       // prologue scratch row stride, floats (16-B rows)
     static constexpr int NS = DP / 2;                       // MFMA k-steps
     static constexpr int NBUF = 2;
     static constexpr int MAIN_FLOATS = (NBUF * BUF_F4 * 4 > WAVES * 32 * XS) ? NBUF * BUF_F4 * 4 : WAVES * 32 * XS;
@@ -170,25 +170,31 @@ struct Geo {
     static constexpr int NEL = DP >= 64 ? DP / 64 : 1;      // scalars per lane in finalize
 };
 
-// code fragments: one ds_read_b128 feeds 4 MFMAs (256 cycles of matrix pipe); keep PF reads in flight and pin the
-// order so the scheduler cannot hoist every read to the top (register pressure).  `hook(g)` is expanded after
-// MFMA group g: VALU / LDS-DMA work placed there issues while the group's MFMAs occupy the matrix pipe.
-template <int DP, typename Hook>
-__device__ __forceinline__ void mfma_tile(f32x16 &acc, const f32x4 *ta, const float (&xf)[DP / 2], Hook hook) {
-    constexpr int NG = DP / 8;
-    constexpr int PF = NG < 3 ? NG : 3;
-    f32x4 a[NG];
+// code fragments: one ds_read_b128 feeds 4 MFMAs (256 cycles of matrix pipe).  `a` is the whole tile's fragment
+// array (compile-time indexed -> registers); reads run PF groups ahead of the MFMAs and the order is pinned so the
+// scheduler cannot hoist every read to the top (register pressure).  Groups [G0, G1) of 8 dims.
+template <int DP>
+struct FragPipe {
+    static constexpr int NG = DP / 8;
+    static constexpr int PF = NG < 3 ? NG : 3;
+};
+
+template <int DP>
+__device__ __forceinline__ void mfma_prefetch(f32x4 (&a)[DP / 8], const f32x4 *ta) {
 #pragma unroll
-    for (int g = 0; g < PF; ++g) a[g] = ta[2 * g];
+    for (int g = 0; g < FragPipe<DP>::PF; ++g) a[g] = ta[2 * g];
+}
+
+template <int DP, int G0, int G1>
+__device__ __forceinline__ void mfma_range(f32x16 &acc, f32x4 (&a)[DP / 8], const f32x4 *ta, const float (&xf)[DP / 2]) {
+    constexpr int NG = FragPipe<DP>::NG, PF = FragPipe<DP>::PF;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int g = G0; g < G1; ++g) {
         if (g + PF < NG) a[g + PF] = ta[2 * (g + PF)];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, xf[4 * g + 0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, xf[4 * g + 1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, xf[4 * g + 2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, xf[4 * g + 3], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        hook(g);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -293,39 +299,75 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
     // ---------------- prologue: this wave's 32 rows -> MFMA fragments in registers ----------------
     // xf[s] = x[row0 + c][2 s + h]   (lane half h holds the k = h operand of MFMA step s)
     float xf[NS];
+    float xn0 = 0.0f;  // |x|^2 of row c: d-ordered fmaf chain (the oracle's sumsq_chain)
     {
+        // Wave-private staging region, no workgroup barriers: a wave's LDS operations execute in order.
+        // Global loads of chunk i+1 are in flight while chunk i goes through LDS.
         float *xs = smem + wave * (32 * XS);
+        constexpr int NCHUNK = DP / CH;
+        constexpr int LPL = CH / 8;  // float4 loads per lane per chunk
+        f32x4 v[2][LPL];
+        auto load_chunk = [&](int ch, f32x4 (&dst)[LPL]) {
 #pragma unroll
-        for (int ch = 0; ch < DP / CH; ++ch) {
-#pragma unroll
-            for (int it = 0; it < CH / 8; ++it) {
+            for (int it = 0; it < LPL; ++it) {
                 const int f = it * 64 + lane;
                 const int r = f / (CH / 4), c4 = f % (CH / 4);
                 long long grow = row0 + r;
                 if (grow >= p.M) grow = p.M - 1;
                 const int d0 = ch * CH + c4 * 4;
                 const float *src = xh + grow * p.x_rs + d0;
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (p.vec_x) {
-                    if (d0 < p.D) v = *(const f32x4 *)src;
+                    if (d0 < p.D) t = *(const f32x4 *)src;
                 } else {
-                    if (d0 + 0 < p.D) v.x = src[0];
-                    if (d0 + 1 < p.D) v.y = src[1];
-                    if (d0 + 2 < p.D) v.z = src[2];
-                    if (d0 + 3 < p.D) v.w = src[3];
+                    if (d0 + 0 < p.D) t.x = src[0];
+                    if (d0 + 1 < p.D) t.y = src[1];
+                    if (d0 + 2 < p.D) t.z = src[2];
+                    if (d0 + 3 < p.D) t.w = src[3];
                 }
-                float *dstp = xs + r * XS + c4 * 4;  // XS is odd: scalar stores, conflict-free strided reads
-                dstp[0] = v.x;
-                dstp[1] = v.y;
-                dstp[2] = v.z;
-                dstp[3] = v.w;
+                dst[it] = t;
             }
-            __syncthreads();
-            const float *rp = xs + c * XS + h;  // this lane's row, its k parity
+        };
+        load_chunk(0, v[0]);
 #pragma unroll
-            for (int u = 0; u < CH / 2; ++u) xf[ch * (CH / 2) + u] = rp[2 * u];
-            __syncthreads();
+        for (int ch = 0; ch < NCHUNK; ++ch) {
+            if (ch + 1 < NCHUNK) load_chunk(ch + 1, v[(ch + 1) & 1]);
+#pragma unroll
+            for (int it = 0; it < LPL; ++it) {
+                const int f = it * 64 + lane;
+                const int r = f / (CH / 4), c4 = f % (CH / 4);
+                *(f32x4 *)(xs + r * XS + c4 * 4) = v[ch & 1][it];  // XS = CH + 4: b128 accesses conflict-free
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const float *rp = xs + c * XS;  // this lane's row (both lane halves read the same row)
+#pragma unroll
+            for (int j = 0; j < CH / 8; ++j) {
+                const f32x4 lo = *(const f32x4 *)(rp + 8 * j);
+                const f32x4 hi = *(const f32x4 *)(rp + 8 * j + 4);
+                if (EUCLID) {
+                    xn0 = fmaf(lo.x, lo.x, xn0);
+                    xn0 = fmaf(lo.y, lo.y, xn0);
+                    xn0 = fmaf(lo.z, lo.z, xn0);
+                    xn0 = fmaf(lo.w, lo.w, xn0);
+                    xn0 = fmaf(hi.x, hi.x, xn0);
+                    xn0 = fmaf(hi.y, hi.y, xn0);
+                    xn0 = fmaf(hi.z, hi.z, xn0);
+                    xn0 = fmaf(hi.w, hi.w, xn0);
+                }
+                // lower half-wave keeps dims 8j..8j+3, upper 8j+4..8j+7; two half-wave exchanges de-interleave
+                // them into the MFMA k-parity layout: lower gets the even dims, upper the odd dims.
+                const f32x4 m = h ? hi : lo;
+                const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(m.x), __float_as_uint(m.y), false, false);
+                const auto zw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m.z), __float_as_uint(m.w), false, false);
+                const int sb = ch * (CH / 2) + 4 * j;
+                xf[sb + 0] = __uint_as_float(xy[0]);  // dim 8j + 0 + h
+                xf[sb + 1] = __uint_as_float(zw[0]);  // dim 8j + 2 + h
+                xf[sb + 2] = __uint_as_float(xy[1]);  // dim 8j + 4 + h
+                xf[sb + 3] = __uint_as_float(zw[1]);  // dim 8j + 6 + h
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next chunk overwrites
         }
+        __syncthreads();  // the staging region is about to be reused as codebook tile buffers
     }
 
     const long long row = row0 + c;
@@ -334,9 +376,12 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
     for (int q = 0; q < (MULTI ? p.Q : 1); ++q) {
         const float *pk = p.packed + (long long)head * p.pk_hs + (long long)q * p.pk_qs;
 
-        // |x|^2 as the diagonal of X X^T: a k-ordered fmaf chain, identical to the oracle's sumsq_chain
+        // |x|^2 of the current residual: stage 0 has it from the prologue; later stages take the diagonal of
+        // X X^T (a k-ordered fmaf chain on the matrix pipe, bit-identical to the oracle's sumsq_chain)
         float b_aug = 1.0f;
-        if (EUCLID) {
+        if (EUCLID && q == 0) {
+            b_aug = h ? 1.0f : xn0;  // B[k=0][row] = |x|^2, B[k=1][row] = 1
+        } else if (EUCLID) {
             f32x16 d = {0};
 #pragma unroll
             for (int s = 0; s < NS; ++s) d = __builtin_amdgcn_mfma_f32_32x32x2f32(xf[s], xf[s], d, 0, 0, 0);
@@ -373,13 +418,20 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
             const int cur = (t - t0) & 1;
             const f32x4 *tb = tile4 + cur * G::BUF_F4;
             acc = (f32x16){0};
-            mfma_tile<DP>(acc, tb + c * RS4 + h, xf, [&](int g) {
-                if (g == 0) {
-                    if (have_prev) tile_epilogue<METRIC, DP>(prev, t - 1, h, p.K, best_t, best_s, best_i);
-                } else if (g == (DP >= 32 ? 2 : 1)) {
-                    if (t + 1 < t1) stage(t + 1, cur ^ 1);
-                }
-            });
+            {
+                constexpr int NG = DP / 8;
+                constexpr int G1 = NG >= 2 ? 1 : NG, G2 = NG >= 4 ? 3 : NG;
+                const f32x4 *ta = tb + c * RS4 + h;
+                f32x4 a[NG];
+                mfma_prefetch<DP>(a, ta);
+                mfma_range<DP, 0, G1>(acc, a, ta, xf);
+                if (have_prev) tile_epilogue<METRIC, DP>(prev, t - 1, h, p.K, best_t, best_s, best_i);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_range<DP, G1, G2>(acc, a, ta, xf);
+                if (t + 1 < t1) stage(t + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_range<DP, G2, NG>(acc, a, ta, xf);
+            }
             if (EUCLID) {
                 const float cnv = ((const float *)tb)[c * RS + DP];
                 const float a_aug = h ? cnv : 1.0f;  // A[code][k=0] = 1, A[code][k=1] = |c|^2
