@@ -353,6 +353,7 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
                     xn0 = fmaf(hi.y, hi.y, xn0);
                     xn0 = fmaf(hi.z, hi.z, xn0);
                     xn0 = fmaf(hi.w, hi.w, xn0);
+                    asm volatile("" : "+v"(xn0));  // pin the chain here: do not keep lo/hi alive to finish it later
                 }
                 // lower half-wave keeps dims 8j..8j+3, upper 8j+4..8j+7; two half-wave exchanges de-interleave
                 // them into the MFMA k-parity layout: lower gets the even dims, upper the odd dims.
