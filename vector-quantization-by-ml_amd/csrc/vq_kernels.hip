@@ -833,7 +833,7 @@ int check_common(const vq_args *a) {
     if (!a) return fail(VQ_E_BADARG, "vq: null args");
     if (a->H <= 0 || a->Q <= 0 || a->M < 0 || a->K <= 0 || a->D <= 0) return fail(VQ_E_BADARG, "vq: non-positive size");
     if (a->metric != VQ_METRIC_EUCLID && a->metric != VQ_METRIC_DOT) return fail(VQ_E_BADARG, "vq: unknown metric");
-    if (!a->x) return fail(VQ_E_BADARG, "vq: x is null");
+    if (!a->x && a->M > 0) return fail(VQ_E_BADARG, "vq: x is null");
     return 0;
 }
 
@@ -1023,9 +1023,9 @@ int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream) {
 int vq_quantize_f32(const vq_args *a, void *stream) {
     int rc = check_common(a);
     if (rc) return rc;
-    if (!a->idx) return fail(VQ_E_BADARG, "vq_quantize: idx is null");
-    if (!a->cb) return fail(VQ_E_BADARG, "vq_quantize: natural codebook is null");
     hipStream_t s = (hipStream_t)stream;
+    if (a->M > 0 && !a->idx) return fail(VQ_E_BADARG, "vq_quantize: idx is null");
+    if (a->M > 0 && !a->cb) return fail(VQ_E_BADARG, "vq_quantize: natural codebook is null");
     if (a->M == 0) {
         if (a->sq_err) hipMemsetAsync(a->sq_err, 0, sizeof(double) * a->Q, s);
         return 0;

@@ -157,8 +157,10 @@ class VectorQuantize(nn.Module):
             x = x.movedim(1, -1)  # b d ... -> b ... d (view)
         spatial = tuple(x.shape[1:-1])
         batch = x.shape[0]
-        x = x.reshape(batch, -1, x.shape[-1])  # b n d  (copy only if the permuted view cannot be flattened)
-        n = x.shape[1]
+        n = 1
+        for extent in spatial:
+            n *= extent
+        x = x.reshape(batch, n, x.shape[-1])  # b n d  (copy only if the permuted view cannot be flattened)
         x = self.project_in(x)
 
         heads, cb = self.heads, self._codebook

@@ -143,7 +143,7 @@ class ResidualVQ(nn.Module):
         cb0 = first._codebook
         training = self.training
         lead, d = x.shape[:-1], x.shape[-1]
-        flat = x.reshape(1, -1, d)
+        flat = x.reshape(1, x.numel() // max(d, 1), d)
         if flat.dtype != torch.float32:
             flat = flat.float()
         Q = self.num_quantizers
