@@ -130,9 +130,36 @@ def kernel_roofline(w, device, mod, x):
                 algorithmic_hbm_bytes_per_launch=(8 * (w.get("codebook_dim") or w["dim"]) + 8 * w.get("Q", 1)) * rows_per_step(w))
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask and cgroup CPU quota, not the machine's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(w, budget_s):
     """The reference's ATen op sequence on the host cores, bounded sample of the same workload."""
     from oracle import ref_path
+
+    cores = usable_cores()
+    torch.set_num_threads(cores)
 
     dim, K = w["dim"], w["K"]
     g = torch.Generator().manual_seed(1234)
@@ -162,9 +189,10 @@ def cpu_baseline(w, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s or it >= 200:
             break
-    return dict(value=round(rows * it / el, 1), unit="vectors/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=round(rows * it / el, 1), unit="vectors/s", cores=cores, kind="port",
                 sample=f"oracle/ref_path.py (reference ATen op sequence: -cdist, argmax, one_hot, gather) on x{list(sample_shape)}, "
-                       f"{it} iterations in {el:.1f} s, torch {torch.__version__} CPU")
+                       f"{it} iterations in {el:.1f} s, torch {torch.__version__} CPU, {cores} threads "
+                       f"(machine reports {os.cpu_count()} cpus)")
 
 
 def sharded_k65536(device, rank, world, steps=5):
@@ -218,11 +246,17 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    device = torch.device(f"cuda:{local_rank}")
+    # rehearsal knobs (1-GPU box): all ranks on cuda:0 over gloo, to exercise the N > 1 code path
+    one_device = os.environ.get("VQ_BENCH_ONE_DEVICE", "0") == "1"
+    backend = os.environ.get("VQ_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda:0" if one_device else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from vector_quantization import native
 

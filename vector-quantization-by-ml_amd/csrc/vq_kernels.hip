@@ -61,6 +61,10 @@ inline int padded_dim(int D) {
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+// A staged LDS tile always carries ~33 KB: 32 codes at Dp >= 256, 64 / 128 / 256 codes at Dp = 128 / 64 / 32, so
+// the per-tile barrier and LDS-DMA issue are amortised over the same number of MFMAs at every dim.
+constexpr int sub_tiles(int DP) { return DP >= 256 ? 1 : 256 / DP; }
+
 // ------------------------------------------------------------------------------------------------
 // packed (value, index) keys: signed 64-bit, MIN wins, lowest index on equal values
 // ------------------------------------------------------------------------------------------------
@@ -95,20 +99,37 @@ __device__ __forceinline__ float key_value(long long key, int metric) {
 __global__ void vq_pack_kernel(const float *__restrict__ cb, long long cb_stride, int K, int Kp, int D, int DP,
                                int metric, float *__restrict__ packed, long long pk_stride) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Kp) return;
     const int RS = DP + 4;
+    float *img = packed + (long long)blockIdx.y * pk_stride;
+    if (k >= Kp) {
+        // the threads past the last row zero the over-copy slack behind the image (read by the tile DMA)
+        const int nslack = kPackSlack / 4;
+        const int j = k - Kp;
+        const int nthreads = gridDim.x * blockDim.x - Kp;
+        for (int i = j; i < nslack; i += nthreads) *(f32x4 *)(img + (long long)Kp * RS + 4 * i) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        return;
+    }
     const float *src = cb + (long long)blockIdx.y * cb_stride + (long long)k * D;
-    float *dst = packed + (long long)blockIdx.y * pk_stride + (long long)k * RS;
+    float *dst = img + (long long)k * RS;
     const float scale = (metric == VQ_METRIC_EUCLID) ? -2.0f : 1.0f;
+    const bool vec = (D % 4 == 0) && (cb_stride % 4 == 0) && (((uintptr_t)cb & 15) == 0);
     float cn = 0.0f;
+#pragma unroll 4
     for (int g = 0; g < DP / 8; ++g) {
         float v[8];
+        if (vec && k < K && 8 * g + 8 <= D) {
+            const f32x4 lo = *(const f32x4 *)(src + 8 * g), hi = *(const f32x4 *)(src + 8 * g + 4);
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+            v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int d = 8 * g + e;
-            v[e] = (k < K && d < D) ? src[d] : 0.0f;
-            cn = fmaf(v[e], v[e], cn);  // d-ordered chain; padded zeros leave it unchanged
+            for (int e = 0; e < 8; ++e) {
+                const int d = 8 * g + e;
+                v[e] = (k < K && d < D) ? src[d] : 0.0f;
+            }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cn = fmaf(v[e], v[e], cn);  // d-ordered chain; padded zeros leave it unchanged
         f32x4 ev = {scale * v[0], scale * v[2], scale * v[4], scale * v[6]};
         f32x4 od = {scale * v[1], scale * v[3], scale * v[5], scale * v[7]};
         *(f32x4 *)(dst + 8 * g) = ev;
@@ -140,6 +161,7 @@ struct SearchParams {
     long long M;
     int K, D, Q;
     int ntiles, tiles_per_split;
+    unsigned pk_bytes;  // bytes of one packed image (buffer descriptor range)
     int mode;
     int ste;
     int vec_x;    // x rows may be read as float4 (D % 4 == 0, strides % 4 == 0, 16-B aligned base)
@@ -154,11 +176,31 @@ __device__ __forceinline__ void glds16(const float *g, lds_f32x4 *l) {
                                      (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
+#ifdef VQ_EXP_STAMPS
+__device__ unsigned long long g_stamps[8192 * 4];
+__device__ unsigned long long g_segs[8192 * 8];
+#define STAMP(i) do { if (lane == 0) g_stamps[(((long long)blockIdx.x * WAVES + wave) & 8191) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// buffer_load_dwordx4 ... lds: `base` + voffset (per lane) + soffset (scalar) -> LDS at l + lane * 16
+__device__ __forceinline__ void lds_dma16(const float *base, unsigned bytes, int voffset, int soffset, lds_f32x4 *l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)l, 16, voffset, soffset, 0, 0);
+#else
+    (void)base; (void)bytes; (void)voffset; (void)soffset; (void)l;
+#endif
+}
+
 template <int DP, int WAVES>
 struct Geo {
     static constexpr int RS = DP + 4;                       // packed row stride, floats
     static constexpr int RS4 = RS / 4;
-    static constexpr int TILE_F4 = kTileCodes * RS / 4;     // float4 per 32-code tile image
+    static constexpr int SUB = sub_tiles(DP);               // 32-code MFMA sub-tiles per staged tile / barrier
+    static constexpr int TILE_CODES = kTileCodes * SUB;
+    static constexpr int TILE_F4 = TILE_CODES * RS / 4;     // float4 per staged tile image
     static constexpr int TILE_CHUNKS = (TILE_F4 + 63) / 64; // 1-KiB wave copies per tile (over-copy)
     static constexpr int BUF_F4 = TILE_CHUNKS * 64;
     static constexpr int CH = DP < 64 ? DP : 64;            // prologue column chunk
@@ -298,6 +340,7 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
 
     // ---------------- prologue: this wave's 32 rows -> MFMA fragments in registers ----------------
     // xf[s] = x[row0 + c][2 s + h]   (lane half h holds the k = h operand of MFMA step s)
+    STAMP(0);
     float xf[NS];
     float xn0 = 0.0f;  // |x|^2 of row c: d-ordered fmaf chain (the oracle's sumsq_chain)
     {
@@ -371,6 +414,7 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
         __syncthreads();  // the staging region is about to be reused as codebook tile buffers
     }
 
+    STAMP(1);
     const long long row = row0 + c;
     const bool row_ok = row < p.M;
 
@@ -402,61 +446,118 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
         const int t0 = blockIdx.z * p.tiles_per_split;
         const int t1 = (t0 + p.tiles_per_split < p.ntiles) ? t0 + p.tiles_per_split : p.ntiles;
 
+        // LDS-DMA of one tile image: buffer_load ... lds with the per-lane part (lane * 16 B) in voffset and the
+        // tile / chunk position in the SCALAR offset -> no vector instructions at all per issue (on gfx950 VALU
+        // work is not free beside f32 MFMA: it executes on the same lanes).
         auto stage = [&](int tile, int buf) {
 #pragma unroll
             for (int i = 0; i < (G::TILE_CHUNKS + WAVES - 1) / WAVES; ++i) {
                 const int ck = i * WAVES + wave;
                 if (ck < G::TILE_CHUNKS)
-                    glds16(pk + ((long long)tile * G::TILE_F4 + ck * 64 + lane) * 4,
-                           tile4_lds + buf * G::BUF_F4 + ck * 64);
+                    lds_dma16(pk, p.pk_bytes, lane * 16, (tile * G::TILE_F4 + ck * 64) * 16,
+                              tile4_lds + buf * G::BUF_F4 + ck * 64);
             }
         };
-        // One tile: Dp/2 MFMAs into `acc`, then the augmented-column MFMA (|x|^2 * 1 + 1 * |c|^2).  Software
-        // pipelined inside the wave: the PREVIOUS tile's reduction (`prev`, finished long ago, so no MFMA drain)
-        // and the NEXT tile's LDS-DMA issue are expanded between MFMA groups, where they issue while the matrix
-        // pipe is busy with this tile.
-        auto run_tile = [&](f32x16 &acc, f32x16 &prev, int t, bool have_prev) {
+        // One 32-code sub-tile: Dp/2 MFMAs into `acc`, then the augmented-column MFMA (|x|^2 * 1 + 1 * |c|^2).
+        // Software pipelined inside the wave: the PREVIOUS sub-tile's reduction (`prev`, finished long ago, so no
+        // MFMA drain) and the NEXT tile's LDS-DMA issue are expanded between MFMA groups, where they issue while
+        // the matrix pipe is busy with this sub-tile.  `u` counts 32-code sub-tiles from code 0.
+        constexpr int SUB = G::SUB;
+        // Roles of the two waves that share a SIMD (8-wave workgroups).  A dependent v_mfma_f32_32x32x2_f32 chain
+        // saturates the matrix pipe by itself, and the SIMD arbitrates by priority then age, so the two waves do
+        // not interleave: one streams its Dp/2 MFMAs, then the other.  Group A (waves 0..3, raised priority) streams
+        // FIRST and does its bookkeeping (this sub-tile's reduction, its share of the next tile's LDS-DMA) at the
+        // END, under B's stream; group B (waves 4..7) does its bookkeeping (previous sub-tile's reduction, DMA
+        // share) FIRST, under A's stream, then streams.  4-wave workgroups keep the interleaved form.
+#ifndef VQ_ROLES
+#define VQ_ROLES 0
+#endif
+        constexpr bool ROLES = (WAVES == 8) && VQ_ROLES;
+        const bool grp_b = ROLES && (wave >= WAVES / 2);
+#ifdef VQ_EXP_STAMPS
+#define EV(k) do { if (blockIdx.x == 300 && lane == 0 && u >= 100 && u < 104) { unsigned long long tn_; \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_) :: "memory"); \
+        g_segs[(wave * 4 + (u - 100)) * 8 + (k)] = tn_; } } while (0)
+#else
+#define EV(k) do { } while (0)
+#endif
+        auto run_sub = [&](f32x16 &acc, f32x16 &prev, int u, bool have_prev) {
+            const int t = u / SUB, st = u % SUB;
             const int cur = (t - t0) & 1;
-            const f32x4 *tb = tile4 + cur * G::BUF_F4;
+            const f32x4 *tb = tile4 + cur * G::BUF_F4 + st * (kTileCodes * RS4);
+            constexpr int NG = DP / 8;
+            const f32x4 *ta = tb + c * RS4 + h;
+            f32x4 a[NG];
             acc = (f32x16){0};
-            {
-                constexpr int NG = DP / 8;
+            EV(0);
+            if (ROLES) {
+                if (grp_b) {
+                    if (have_prev) tile_epilogue<METRIC, DP>(prev, u - 1, h, p.K, best_t, best_s, best_i);
+                    EV(1);
+                    if (st == 0 && t + 1 < t1) stage(t + 1, cur ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    EV(2);
+                } else {
+#if VQ_ROLES == 2
+                    __builtin_amdgcn_s_setprio(1);
+#endif
+                }
+                mfma_prefetch<DP>(a, ta);
+                mfma_range<DP, 0, 1>(acc, a, ta, xf);
+                EV(3);
+                mfma_range<DP, 1, NG>(acc, a, ta, xf);
+                EV(4);
+            } else {
                 constexpr int G1 = NG >= 2 ? 1 : NG, G2 = NG >= 4 ? 3 : NG;
-                const f32x4 *ta = tb + c * RS4 + h;
-                f32x4 a[NG];
                 mfma_prefetch<DP>(a, ta);
                 mfma_range<DP, 0, G1>(acc, a, ta, xf);
-                if (have_prev) tile_epilogue<METRIC, DP>(prev, t - 1, h, p.K, best_t, best_s, best_i);
+                EV(1);
+                if (have_prev) tile_epilogue<METRIC, DP>(prev, u - 1, h, p.K, best_t, best_s, best_i);
                 __builtin_amdgcn_sched_barrier(0);
+                EV(2);
                 mfma_range<DP, G1, G2>(acc, a, ta, xf);
-                if (t + 1 < t1) stage(t + 1, cur ^ 1);
+                EV(3);
+                if (st == 0 && t + 1 < t1) stage(t + 1, cur ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
+                EV(4);
                 mfma_range<DP, G2, NG>(acc, a, ta, xf);
             }
+            EV(5);
             if (EUCLID) {
                 const float cnv = ((const float *)tb)[c * RS + DP];
                 const float a_aug = h ? cnv : 1.0f;  // A[code][k=0] = 1, A[code][k=1] = |c|^2
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, acc, 0, 0, 0);
             }
-            __syncthreads();  // next tile landed (vmcnt(0)) and everybody is done reading this one
+            if (ROLES && !grp_b) {
+#if VQ_ROLES == 2
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                if (st == 0 && t + 1 < t1) stage(t + 1, cur ^ 1);
+                tile_epilogue<METRIC, DP>(acc, u, h, p.K, best_t, best_s, best_i);
+            }
+            EV(6);
+            if (st == SUB - 1) __syncthreads();  // next tile landed (vmcnt(0)), everybody is done reading this one
+            EV(7);
         };
 
         stage(t0, 0);
         __syncthreads();
         {
             f32x16 acc0, acc1;
-            int t = t0;
+            int u = t0 * SUB;
+            const int u1 = t1 * SUB;
             bool have_prev = false;
-            for (; t + 1 < t1; t += 2) {
-                run_tile(acc0, acc1, t, have_prev);
-                run_tile(acc1, acc0, t + 1, true);
+            for (; u + 1 < u1; u += 2) {
+                run_sub(acc0, acc1, u, have_prev);
+                run_sub(acc1, acc0, u + 1, true);
                 have_prev = true;
             }
-            if (t < t1) {
-                run_tile(acc0, acc1, t, have_prev);
-                tile_epilogue<METRIC, DP>(acc0, t, h, p.K, best_t, best_s, best_i);
+            const bool pipelined = !ROLES || grp_b;  // group A reduces every sub-tile in place
+            if (u < u1) {
+                run_sub(acc0, acc1, u, have_prev);
+                if (pipelined) tile_epilogue<METRIC, DP>(acc0, u, h, p.K, best_t, best_s, best_i);
             } else if (have_prev) {
-                tile_epilogue<METRIC, DP>(acc1, t - 1, h, p.K, best_t, best_s, best_i);
+                if (pipelined) tile_epilogue<METRIC, DP>(acc1, u - 1, h, p.K, best_t, best_s, best_i);
             }
         }
 
@@ -513,6 +614,7 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
         }
     }
 
+    STAMP(2);
     if (p.mode == kModeKeys) return;
     if (p.out == nullptr && p.loss_part == nullptr) return;
 
@@ -619,6 +721,7 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
             }
         }
     }
+    STAMP(3);
     if (p.loss_part) {
         float *lp = p.loss_part + (((long long)head * gridDim.x + blockIdx.x) * WAVES + wave) * p.Q;
         for (int q = 0; q < (MULTI ? p.Q : 1); ++q) {
@@ -850,8 +953,12 @@ void fill_search_params(SearchParams &p, const vq_args *a) {
     p.idx = (long long *)a->idx; p.idx_rs = a->idx_rs; p.idx_hs = a->idx_hs; p.idx_qs = a->idx_qs;
     p.best = a->best;
     p.M = a->M; p.K = a->K; p.D = a->D; p.Q = a->Q;
-    p.ntiles = (a->K + kTileCodes - 1) / kTileCodes;
+    {
+        const int tc = kTileCodes * sub_tiles(padded_dim(a->D) ? padded_dim(a->D) : 256);
+        p.ntiles = (a->K + tc - 1) / tc;
+    }
     p.tiles_per_split = p.ntiles;
+    p.pk_bytes = (unsigned)(vq_packed_floats(a->K, a->D) * 4);
     p.ste = (a->flags & VQ_F_STE) ? 1 : 0;
     p.vec_x = (a->D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x)) ? 1 : 0;
     p.vec_fin = (p.vec_x && (!a->out || (a->out_rs % 4 == 0 && a->out_hs % 4 == 0 && aligned16(a->out))) &&
@@ -932,6 +1039,15 @@ extern "C" {
 
 const char *vq_last_error(void) { return g_err; }
 
+#ifdef VQ_EXP_STAMPS
+int vq_debug_read_stamps(unsigned long long *host, size_t n) {  // diagnostic build only
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long));
+}
+int vq_debug_read_segs(unsigned long long *host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_segs), n * sizeof(unsigned long long));
+}
+#endif
+
 int vq_device_info(char *buf, size_t n) {
     const DevInfo &di = dev_info();
     if (!di.ok) return fail(VQ_E_NODEVICE, "vq: no HIP device");
@@ -943,7 +1059,7 @@ int64_t vq_packed_floats(int K, int D) {
     if (K <= 0 || D <= 0) return 0;
     const int DP = padded_dim(D);
     if (DP == 0) return 4;  // scalar kernel reads the natural codebook
-    return (int64_t)round_up(K, kTileCodes) * (DP + 4) + kPackSlack;
+    return (int64_t)round_up(K, kTileCodes * sub_tiles(DP)) * (DP + 4) + kPackSlack;
 }
 
 int64_t vq_workspace_bytes(int H, int64_t M, int Q) {
@@ -958,15 +1074,11 @@ int vq_pack_codebooks_f32(const float *cb, int n_codebooks, int64_t cb_stride, i
     const int DP = padded_dim(D);
     if (DP == 0) return 0;  // nothing to pack: the scalar kernel is used for D > 512
     if (!aligned16(packed)) return fail(VQ_E_BADARG, "vq_pack: packed buffer must be 16-byte aligned");
-    const int Kp = round_up(K, kTileCodes);
+    const int Kp = round_up(K, kTileCodes * sub_tiles(DP));
     const long long pk_stride = vq_packed_floats(K, D);
     hipStream_t s = (hipStream_t)stream;
-    // zero the slack so that over-copies read defined data
-    for (int n = 0; n < n_codebooks; ++n) {
-        hipError_t e = hipMemsetAsync(packed + n * pk_stride + (long long)Kp * (DP + 4), 0, kPackSlack * 4, s);
-        if (e != hipSuccess) return hip_fail(e, "vq_pack memset");
-    }
-    hipLaunchKernelGGL(vq_pack_kernel, dim3((Kp + 63) / 64, n_codebooks), dim3(64), 0, s, cb, (long long)cb_stride, K, Kp,
+    // grid covers Kp rows plus at least one extra block whose threads zero the over-copy slack
+    hipLaunchKernelGGL(vq_pack_kernel, dim3(Kp / 64 + 1, n_codebooks), dim3(64), 0, s, cb, (long long)cb_stride, K, Kp,
                        D, DP, metric, packed, pk_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "vq_pack launch");
@@ -1052,9 +1164,9 @@ int vq_quantize_f32(const vq_args *a, void *stream) {
             waves = 4;
             wgs = (long long)a->H * ((a->M + 127) / 128);
         }
-        const int ntiles = (a->K + kTileCodes - 1) / kTileCodes;
+        const int ntiles = (a->K + kTileCodes * sub_tiles(DP) - 1) / (kTileCodes * sub_tiles(DP));
         // few workgroups and a long sweep: splitting K over workgroups fills the chip (Q == 1 only)
-        if (a->Q == 1 && wgs * 2 <= cus && ntiles >= 8) fused = false;
+        if (a->Q == 1 && wgs * 2 <= cus && ntiles * sub_tiles(DP) >= 8 && ntiles >= 2) fused = false;
         if ((a->flags & VQ_F_FORCE_SPLIT) && a->Q == 1) fused = false;
     }
 
