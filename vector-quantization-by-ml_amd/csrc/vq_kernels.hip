@@ -341,6 +341,9 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
     // ---------------- prologue: this wave's 32 rows -> MFMA fragments in registers ----------------
     // xf[s] = x[row0 + c][2 s + h]   (lane half h holds the k = h operand of MFMA step s)
     STAMP(0);
+    // Memory-bound phases (prologue, finalize) run at raised priority: when another workgroup's wave is streaming
+    // MFMAs on the same SIMD, these few load/store/LDS instructions must not be starved by it.
+    __builtin_amdgcn_s_setprio(2);
     float xf[NS];
     float xn0 = 0.0f;  // |x|^2 of row c: d-ordered fmaf chain (the oracle's sumsq_chain)
     {
@@ -415,6 +418,7 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
     }
 
     STAMP(1);
+    __builtin_amdgcn_s_setprio(0);
     const long long row = row0 + c;
     const bool row_ok = row < p.M;
 
@@ -615,6 +619,7 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
     }
 
     STAMP(2);
+    __builtin_amdgcn_s_setprio(2);
     if (p.mode == kModeKeys) return;
     if (p.out == nullptr && p.loss_part == nullptr) return;
 
@@ -630,56 +635,81 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
     float e0 = 0.0f;
     const float *cbh = p.cb + (long long)head * p.cb_hs;
     float *outh = p.out ? p.out + (long long)head * p.out_hs : nullptr;
-    for (int rr = 0; rr < 32; ++rr) {
-        const long long grow = row0 + rr;
-        if (grow >= p.M) break;  // wave-uniform
-        const float *xr = xh + grow * p.x_rs;
-        float *orow = outh ? outh + grow * p.out_rs : nullptr;
-        if (p.vec_fin) {
-            f32x4 r[G::NCH4], o[G::NCH4];
+    const int nrows = (p.M - row0 >= 32) ? 32 : (int)(p.M - row0);  // wave-uniform, >= 1 ... rows of this wave
+    constexpr int RB = 4;  // rows in flight: the gathers are latency-bound, so issue RB rows' loads before using them
+    for (int rr0 = 0; rr0 < (p.vec_fin ? nrows : 0); rr0 += RB) {
+        f32x4 r[RB][G::NCH4], o[RB][G::NCH4];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int rr = (rr0 + k < nrows) ? rr0 + k : nrows - 1;  // clamp: duplicates are computed, not stored
+            const float *xr = xh + (row0 + rr) * p.x_rs;
 #pragma unroll
             for (int j = 0; j < G::NCH4; ++j) {
                 const int d = 4 * (lane + 64 * j);
-                o[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-                r[j] = o[j];
-                if (need_r && d < p.D) r[j] = *(const f32x4 *)(xr + d);
+                o[k][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                r[k][j] = o[k][j];
+                if (need_r && d < p.D) r[k][j] = *(const f32x4 *)(xr + d);
             }
-            for (int q = 0; q < (MULTI ? p.Q : 1); ++q) {
+        }
+        for (int q = 0; q < (MULTI ? p.Q : 1); ++q) {
+            f32x4 cv[RB][G::NCH4];
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int rr = (rr0 + k < nrows) ? rr0 + k : nrows - 1;
                 const int i = sidx[(wave * p.Q + q) * 32 + rr];
                 const float *crow = cbh + (long long)q * p.cb_qs + (long long)i * p.D;
-                float e = 0.0f;
 #pragma unroll
                 for (int j = 0; j < G::NCH4; ++j) {
                     const int d = 4 * (lane + 64 * j);
-                    if (d < p.D) {
-                        const f32x4 cv = *(const f32x4 *)(crow + d);
-                        f32x4 quant = cv;
-                        if (need_r) {
-                            const f32x4 diff = cv - r[j];
+                    cv[k][j] = (d < p.D) ? *(const f32x4 *)(crow + d) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+            float e = 0.0f;
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const bool live = rr0 + k < nrows;
+#pragma unroll
+                for (int j = 0; j < G::NCH4; ++j) {
+                    f32x4 quant = cv[k][j];
+                    if (need_r) {
+                        const f32x4 diff = cv[k][j] - r[k][j];
+                        if (live) {
                             e = fmaf(diff.x, diff.x, e);
                             e = fmaf(diff.y, diff.y, e);
                             e = fmaf(diff.z, diff.z, e);
                             e = fmaf(diff.w, diff.w, e);
-                            if (p.ste) quant = r[j] + diff;
-                            r[j] = r[j] - quant;
                         }
-                        o[j] = o[j] + quant;
+                        if (p.ste) quant = r[k][j] + diff;
+                        r[k][j] = r[k][j] - quant;
+                    }
+                    o[k][j] = o[k][j] + quant;
+                }
+            }
+            if (MULTI) {
+                if (p.loss_part) lerr[q * 64] += e;
+            } else {
+                e0 += e;
+            }
+        }
+        if (outh) {
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                if (rr0 + k < nrows) {
+                    float *orow = outh + (row0 + rr0 + k) * p.out_rs;
+#pragma unroll
+                    for (int j = 0; j < G::NCH4; ++j) {
+                        const int d = 4 * (lane + 64 * j);
+                        if (d < p.D) *(f32x4 *)(orow + d) = o[k][j];
                     }
                 }
-                if (MULTI) {
-                    if (p.loss_part) lerr[q * 64] += e;
-                } else {
-                    e0 += e;
-                }
             }
-            if (orow) {
-#pragma unroll
-                for (int j = 0; j < G::NCH4; ++j) {
-                    const int d = 4 * (lane + 64 * j);
-                    if (d < p.D) *(f32x4 *)(orow + d) = o[j];
-                }
-            }
-        } else {
+        }
+    }
+    for (int rr = 0; rr < (p.vec_fin ? 0 : nrows); ++rr) {
+        const long long grow = row0 + rr;
+        const float *xr = xh + grow * p.x_rs;
+        float *orow = outh ? outh + grow * p.out_rs : nullptr;
+        {
             float r[G::NEL], o[G::NEL];
 #pragma unroll
             for (int j = 0; j < G::NEL; ++j) {
