@@ -118,6 +118,21 @@ int vq_search_keys_f32(const vq_args *a, int64_t idx_offset, int64_t *keys, void
  */
 int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream);
 
+/*
+ * Training-state step that FOLLOWS the hot path -- exponential-moving-average codebook update.
+ * vq_ema_accumulate_f32: counts[h*K + k] += 1 and sums[(h*K + k)*D + d] += x[h, m, d] for every row m assigned to
+ *   code k = idx[h*idx_hs + m*idx_rs] (rows with mask[h*M + m] == 0 are skipped; mask may be NULL).  The caller
+ *   zeroes counts / sums (and all-reduces them across replicas when codebooks are synchronised).
+ *   Replaces embed_onehot.sum(1) and einsum("h n d, h n c -> h c d") -- codebooks.py:405-415 -- without the one-hot.
+ * vq_ema_update_f32: cluster_size.lerp_(counts, 1-decay); embed_avg.lerp_(sums, 1-decay); embeddings =
+ *   [l2norm](embed_avg / laplace_smoothing(cluster_size) * total) -- codebooks.py:411,417-425.  total_scratch: H floats.
+ * Float atomics: the sums are exact up to fp32 summation order (run-to-run differences at the 1e-7 relative level).
+ */
+int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs, int64_t idx_hs,
+                          const uint8_t *mask, int H, int64_t M, int K, int D, float *counts, float *sums, void *stream);
+int vq_ema_update_f32(float *cluster_size, float *embed_avg, float *embeddings, const float *counts, const float *sums,
+                      float *total_scratch, int H, int K, int D, float decay, float eps, int l2norm, void *stream);
+
 const char *vq_last_error(void);
 int vq_device_info(char *buf, size_t n); /* "gfx950 ... CUs" of the current device */
 

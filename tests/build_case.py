@@ -30,7 +30,8 @@ def build(case, arrays=None, device="cpu"):
         h = heads if separate else 1
         params = CodebookParams(dim=d, codebook_size=K, use_cosine_sim=case.get("use_cosine_sim", False),
                                 transform_input=case.get("transform_input", "identity"),
-                                weights_regularization=case.get("weights_regularization", "identity"))
+                                weights_regularization=case.get("weights_regularization", "identity"),
+                                **case.get("cb_extra", {}))
         mod = vq.VectorQuantize(dim=dim, codebook_params=params, codebook_dim=codebook_dim, heads=heads,
                                 separate_codebook_per_head=separate, channel_last=case.get("channel_last", True))
         cb = make_codebook(h, K, d, case["cls"])
@@ -38,6 +39,7 @@ def build(case, arrays=None, device="cpu"):
             cb = l2norm(cb)
         with torch.no_grad():
             mod._codebook.embeddings.copy_(cb)
+            mod._codebook.embed_avg.copy_(cb)
             if mod.has_projections:
                 assert arrays is not None
                 mod.project_in.weight.copy_(torch.from_numpy(arrays["proj_in_w"]))
@@ -49,12 +51,14 @@ def build(case, arrays=None, device="cpu"):
     elif kind == "rvq":
         dim, K, Q = case["dim"], case["K"], case["Q"]
         shared = case.get("shared_codebook", False)
-        mod = vq.ResidualVQ(dim=dim, num_quantizers=Q, codebook_params=CodebookParams(dim=dim, codebook_size=K),
+        mod = vq.ResidualVQ(dim=dim, num_quantizers=Q,
+                            codebook_params=CodebookParams(dim=dim, codebook_size=K, **case.get("cb_extra", {})),
                             shared_codebook=shared)
         cb = make_rvq_codebooks(Q, K, dim, case["cls"])
         with torch.no_grad():
             for i, layer in enumerate(mod.layers):
                 layer._codebook.embeddings.copy_(cb[0 if shared else i][None])
+                layer._codebook.embed_avg.copy_(cb[0 if shared else i][None])
         if case.get("return_all_codes", False):
             kwargs["return_all_codes"] = True
     elif kind == "grvq":
@@ -74,7 +78,7 @@ def build(case, arrays=None, device="cpu"):
         raise ValueError(kind)
     if case["training"]:
         mod.train()
-        kwargs["freeze_codebook"] = True
+        kwargs["freeze_codebook"] = case.get("freeze_codebook", True)
     else:
         mod.eval()
     return mod.to(device), x.to(device), kwargs, cb

@@ -28,7 +28,7 @@ def certify_near_ties(x_rows, cb, got_idx, ref_idx, metric_dot=False, ulps=8):
     return len(bad), worst
 
 
-def compare(case, arrays, meta, outputs, x, cb):
+def compare(case, arrays, meta, outputs, x, cb, mod=None):
     quantize, idx, loss = outputs[:3]
     quantize, idx, loss = quantize.detach().cpu(), idx.detach().cpu(), loss.detach().cpu()
     assert list(quantize.shape) == meta["q_shape"], (quantize.shape, meta["q_shape"])
@@ -57,6 +57,17 @@ def compare(case, arrays, meta, outputs, x, cb):
             np.testing.assert_allclose(quantize.numpy(), arrays["q_full"], atol=Q_TOL, rtol=0)
         s = float(quantize.double().sum())
         assert abs(s - meta["q_checksum"][0]) <= 1e-5 * max(1.0, meta["q_checksum"][1]), (s, meta["q_checksum"])
+    if "ema_embeddings" in arrays and mod is not None:
+        if case["kind"] == "rvq":
+            emb = torch.stack([l._codebook.embeddings for l in mod.layers])
+            avg = torch.stack([l._codebook.embed_avg for l in mod.layers])
+            cs = torch.stack([l._codebook.cluster_size for l in mod.layers])
+        else:
+            emb, avg, cs = mod._codebook.embeddings, mod._codebook.embed_avg, mod._codebook.cluster_size
+        # training-state step: statistics are sums over hundreds of rows -> relative tolerance on fp32 order
+        np.testing.assert_allclose(cs.detach().cpu().numpy(), arrays["ema_cluster_size"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(avg.detach().cpu().numpy(), arrays["ema_embed_avg"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(emb.detach().cpu().numpy(), arrays["ema_embeddings"], rtol=1e-4, atol=1e-5)
     if "all_codes" in arrays and len(outputs) > 3:
         np.testing.assert_allclose(outputs[3].detach().cpu().numpy(), arrays["all_codes"], atol=Q_TOL, rtol=0)
     return n_mismatch

@@ -70,6 +70,16 @@ CASES = [
     _rvq("rvq_shared", 64, 4, 256, (2, 128, 64), "S", shared_codebook=True),
     _rvq("rvq_allcodes", 32, 3, 64, (2, 20, 32), "S", return_all_codes=True),
     dict(name="grvq", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=False),
+    # --- training-state step after the hot path: EMA update, no dead-code re-seeding (RNG) --
+    _vq("ema_S", 64, 256, (8, 256, 64), "S", training=True, freeze_codebook=False, cb_extra=dict(threshold_ema_dead_code=0)),
+    _vq("ema_mh_S", 128, 128, (4, 64, 128), "S", training=True, freeze_codebook=False, heads=2, codebook_dim=64,
+        separate_codebook_per_head=True, cb_extra=dict(threshold_ema_dead_code=0, decay=0.9)),
+    _vq("ema_cos_l2_S", 64, 128, (4, 128, 64), "S", training=True, freeze_codebook=False, use_cosine_sim=True,
+        transform_input="l2norm", weights_regularization="l2norm", cb_extra=dict(threshold_ema_dead_code=0)),
+    _vq("ema_mask_S", 32, 64, (3, 40, 32), "S", training=True, freeze_codebook=False, mask=True,
+        cb_extra=dict(threshold_ema_dead_code=0)),
+    _rvq("ema_rvq_S", 64, 3, 128, (2, 128, 64), "S", training=True, freeze_codebook=False,
+         cb_extra=dict(threshold_ema_dead_code=0)),
     # --- cfg5: K=65536, D=512 (M reduced); the sharded search must reproduce the full-codebook idx --
     _vq("cfg5_S", 512, 65536, (1, 64, 512), "S"),
 ]

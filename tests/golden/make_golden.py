@@ -70,6 +70,7 @@ def run_vq(ref, ref_cb, c):
         dim=d, codebook_size=K, use_cosine_sim=use_cos,
         transform_input=c.get("transform_input", "identity"),
         weights_regularization=c.get("weights_regularization", "identity"),
+        **c.get("cb_extra", {}),
     )
     torch.manual_seed(777)
     mod = ref.VectorQuantize(dim=dim, codebook_params=params, codebook_dim=codebook_dim, heads=heads,
@@ -79,6 +80,7 @@ def run_vq(ref, ref_cb, c):
         cb = l2norm(cb)
     with torch.no_grad():
         mod._codebook.embeddings.copy_(cb)
+        mod._codebook.embed_avg.copy_(cb)
     x = make_x(c["x_shape"], c["cls"])
     stash = {}
 
@@ -94,13 +96,17 @@ def run_vq(ref, ref_cb, c):
         kwargs["mask"] = mask
     if c["training"]:
         mod.train()
-        kwargs["freeze_codebook"] = True
+        kwargs["freeze_codebook"] = c.get("freeze_codebook", True)
     else:
         mod.eval()
     with torch.no_grad():
         q, idx, loss = mod(x, **kwargs)
     arrays = dict(idx=idx.numpy().astype(np.int32), loss=loss.detach().numpy().astype(np.float32),
                   ref_best=stash["best"].numpy().astype(np.float32))
+    if c["training"] and not c.get("freeze_codebook", True):
+        arrays["ema_embeddings"] = mod._codebook.embeddings.detach().numpy().copy()
+        arrays["ema_embed_avg"] = mod._codebook.embed_avg.detach().numpy().copy()
+        arrays["ema_cluster_size"] = mod._codebook.cluster_size.detach().numpy().copy()
     feat_last = q.shape[-1] if c.get("channel_last", True) else None
     qcl = q if c.get("channel_last", True) else q.movedim(1, -1)
     rows, vals = sample_rows(qcl, qcl.shape[-1])
@@ -121,18 +127,19 @@ def run_vq(ref, ref_cb, c):
 
 def run_rvq(ref, ref_cb, c):
     dim, K, Q = c["dim"], c["K"], c["Q"]
-    params = ref_cb.CodebookParams(dim=dim, codebook_size=K)
+    params = ref_cb.CodebookParams(dim=dim, codebook_size=K, **c.get("cb_extra", {}))
     shared = c.get("shared_codebook", False)
     mod = ref.ResidualVQ(dim=dim, num_quantizers=Q, codebook_params=params, shared_codebook=shared)
     cbs = make_rvq_codebooks(Q, K, dim, c["cls"])
     with torch.no_grad():
         for i, layer in enumerate(mod.layers):
             layer._codebook.embeddings.copy_(cbs[0 if shared else i][None])
+            layer._codebook.embed_avg.copy_(cbs[0 if shared else i][None])
     x = make_x(c["x_shape"], c["cls"])
     kwargs = {}
     if c["training"]:
         mod.train()
-        kwargs["freeze_codebook"] = True
+        kwargs["freeze_codebook"] = c.get("freeze_codebook", True)
     else:
         mod.eval()
     if c.get("return_all_codes", False):
@@ -147,6 +154,10 @@ def run_rvq(ref, ref_cb, c):
         arrays["q_full"] = q.detach().numpy().copy()
     if len(out) > 3:
         arrays["all_codes"] = out[3].detach().numpy().copy()
+    if c["training"] and not c.get("freeze_codebook", True):
+        arrays["ema_embeddings"] = torch.stack([l._codebook.embeddings for l in mod.layers]).detach().numpy().copy()
+        arrays["ema_embed_avg"] = torch.stack([l._codebook.embed_avg for l in mod.layers]).detach().numpy().copy()
+        arrays["ema_cluster_size"] = torch.stack([l._codebook.cluster_size for l in mod.layers]).detach().numpy().copy()
     meta = dict(x_checksum=checksum(x), cb_checksum=checksum(cbs), q_checksum=checksum(q),
                 q_shape=list(q.shape), idx_shape=list(idx.shape))
     return arrays, meta

@@ -31,7 +31,7 @@ def test_module_matches_reference_golden_on_gpu(case):
     with torch.no_grad():
         outputs = mod(x, **kwargs)
     torch.cuda.synchronize()
-    compare(case, arrays, meta, outputs, x, cb)
+    compare(case, arrays, meta, outputs, x, cb, mod)
 
 
 def test_gpu_equals_oracle_backend_on_all_cases(oracle):
@@ -54,8 +54,12 @@ def test_gpu_equals_oracle_backend_on_all_cases(oracle):
         finally:
             search.set_backend(None)
         np.testing.assert_array_equal(got[1].cpu().numpy(), ref[1].numpy(), err_msg=case["name"])
-        if not mod.__dict__.get("has_projections", False) and not case.get("codebook_dim") and case["name"] != "proj_mh":
+        exact = (not mod.__dict__.get("has_projections", False) and not case.get("codebook_dim") and case["name"] != "proj_mh"
+                 and not (case["training"] and case.get("transform_input") == "l2norm"))  # F.normalize differs GPU vs CPU
+        if exact:
             np.testing.assert_array_equal(got[0].cpu().numpy(), ref[0].numpy(), err_msg=case["name"])
+        else:
+            np.testing.assert_allclose(got[0].cpu().numpy(), ref[0].numpy(), atol=1e-5, err_msg=case["name"])
         np.testing.assert_allclose(got[2].cpu().numpy(), ref[2].numpy(), atol=1e-6, err_msg=case["name"])
 
 

@@ -34,4 +34,4 @@ def test_module_matches_reference_golden(case):
     ok, got = checksum_close(cb, meta["cb_checksum"])
     assert ok, f"codebook regeneration drifted: {got} vs {meta['cb_checksum']}"
     outputs = mod(x, **kwargs)
-    compare(case, arrays, meta, outputs, x, cb)
+    compare(case, arrays, meta, outputs, x, cb, mod)

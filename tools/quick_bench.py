@@ -29,10 +29,33 @@ def bench(M, K, D, H=1, Q=1, iters=10, flags=0, want_out=True):
     e.record(); torch.cuda.synchronize()
     print(f"    pack: {s.elapsed_time(e)/iters*1e3:.1f} us")
 
+def bench_ema(M, K, D, H=1, iters=10):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu"); g.manual_seed(0)
+    x = torch.randn((H, M, D), generator=g).to(dev)
+    idx = torch.randint(0, K, (H, M), generator=g).to(dev)
+    cs = torch.zeros((H, K), device=dev); avg = torch.randn((H, K, D), generator=g).to(dev); emb = avg.clone()
+    for _ in range(2):
+        c, s = native.ema_accumulate(x, idx, K); native.ema_update(cs, avg, emb, c, s, 0.8, 1e-5, False)
+    torch.cuda.synchronize()
+    s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s0.record()
+    for _ in range(iters):
+        c, s = native.ema_accumulate(x, idx, K); native.ema_update(cs, avg, emb, c, s, 0.8, 1e-5, False)
+    e0.record(); torch.cuda.synchronize()
+    ms = s0.elapsed_time(e0) / iters
+    gb = H * M * D * 4 / 1e9
+    print(f"EMA step M={M} K={K} D={D} H={H}: {ms:.3f} ms  ({gb/ms*1e3:.0f} GB/s of x; atomic-add bytes = x bytes)")
+
+
 if __name__ == "__main__":
     print(native.device_info())
     cfgs = [(262144, 1024, 256), (262144, 8192, 256), (65536, 8192, 64, 8), (65536, 1024, 256, 1, 8), (8192, 65536, 512), (8192, 256, 64)]
     if len(sys.argv) > 1:
         cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
-    for c in cfgs:
-        bench(*c)
+    if os.environ.get("VQ_BENCH_EMA"):
+        bench_ema(262144, 1024, 256)
+        bench_ema(65536, 8192, 64, 8)
+    else:
+        for c in cfgs:
+            bench(*c)

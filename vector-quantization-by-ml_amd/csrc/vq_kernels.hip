@@ -888,6 +888,91 @@ __global__ void __launch_bounds__(256) vq_loss_reduce_kernel(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// training-state step that follows the hot path: exponential-moving-average update
+//   counts[h,k]  = #rows of head h assigned to code k            (reference: embed_onehot.sum(1), codebooks.py:408)
+//   sums[h,k,:]  = sum of those rows                              (einsum("h n d, h n c -> h c d"), codebooks.py:413)
+// The reference builds both through the [h, M, K] one-hot tensor; here they are a scatter-add with float atomics
+// shaped for the memory-side atomic units: one dword per lane, 256 contiguous bytes per wave instruction.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vq_ema_accumulate_kernel(const float *__restrict__ x, long long x_rs, long long x_hs,
+                                                                const long long *__restrict__ idx, long long idx_rs,
+                                                                long long idx_hs, const unsigned char *__restrict__ mask,
+                                                                long long M, int K, int D, float *__restrict__ counts,
+                                                                float *__restrict__ sums) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int head = blockIdx.y;
+    const long long nw = (long long)gridDim.x * 4;
+    const float *xh = x + (long long)head * x_hs;
+    const long long *ih = idx + (long long)head * idx_hs;
+    float *ch = counts + (long long)head * K;
+    float *sh = sums + (long long)head * K * D;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < M; row += nw) {
+        if (mask && !mask[(long long)head * M + row]) continue;  // wave-uniform
+        const long long k = ih[row * idx_rs];
+        if (k < 0 || k >= K) continue;
+        const float *xr = xh + row * x_rs;
+        float *dst = sh + k * D;
+        for (int d = lane; d < D; d += 64) atomicAdd(dst + d, xr[d]);
+        if (lane == 0) atomicAdd(ch + k, 1.0f);
+    }
+}
+
+// cluster_size <- lerp(cluster_size, counts, 1 - decay);  total[h] = sum_k cluster_size      (codebooks.py:411,419-421)
+__global__ void __launch_bounds__(256) vq_ema_sizes_kernel(float *__restrict__ cluster_size, const float *__restrict__ counts,
+                                                           int K, float weight, float *__restrict__ total) {
+    __shared__ float sh[256];
+    const int head = blockIdx.x;
+    float s = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float old = cluster_size[(long long)head * K + k];
+        const float nw = old + weight * (counts[(long long)head * K + k] - old);
+        cluster_size[(long long)head * K + k] = nw;
+        s += nw;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[head] = sh[0];
+}
+
+// embed_avg <- lerp(embed_avg, sums, 1 - decay); embeddings <- [l2norm](embed_avg / laplace-smoothed size)
+// one wave per code row                                                             (codebooks.py:417-425)
+__global__ void __launch_bounds__(256) vq_ema_codes_kernel(const float *__restrict__ cluster_size, const float *__restrict__ total,
+                                                           float *__restrict__ embed_avg, const float *__restrict__ sums,
+                                                           float *__restrict__ embeddings, int H, int K, int D, float weight,
+                                                           float eps, int l2norm) {
+    const int lane = threadIdx.x & 63;
+    const long long rowid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rowid >= (long long)H * K) return;
+    const int head = (int)(rowid / K);
+    const float tot = total[head];
+    const float cs = cluster_size[rowid];
+    const float smoothed = (cs + eps) / (tot + (float)K * eps) * tot;
+    float *avg = embed_avg + rowid * D;
+    const float *sm = sums + rowid * D;
+    float *emb = embeddings + rowid * D;
+    float nrm = 0.0f;
+    for (int d = lane; d < D; d += 64) {
+        const float old = avg[d];
+        const float a = old + weight * (sm[d] - old);
+        avg[d] = a;
+        const float e = a / smoothed;
+        emb[d] = e;
+        nrm = fmaf(e, e, nrm);
+    }
+    if (l2norm) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nrm += __shfl_xor(nrm, o);
+        const float inv = 1.0f / fmaxf(sqrtf(nrm), 1e-12f);
+        for (int d = lane; d < D; d += 64) emb[d] = emb[d] * inv;  // same lane wrote it
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 struct DevInfo {
@@ -1033,6 +1118,8 @@ int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hip
         return 0;
     }
     if (!a->packed) return fail(VQ_E_BADARG, "vq: packed codebook is null");
+    if (vq_packed_floats(a->K, a->D) * 4 >= (1ll << 31))
+        return fail(VQ_E_UNSUPPORTED, "vq: packed codebook image >= 2 GiB (shard the codebook)");
     SearchParams p;
     fill_search_params(p, a);
     p.mode = kModeKeys;
@@ -1202,6 +1289,8 @@ int vq_quantize_f32(const vq_args *a, void *stream) {
 
     if (fused) {
         if (!a->packed) return fail(VQ_E_BADARG, "vq_quantize: packed codebook is null");
+        if (vq_packed_floats(a->K, a->D) * 4 >= (1ll << 31))
+            return fail(VQ_E_UNSUPPORTED, "vq_quantize: packed codebook image >= 2 GiB (shard the codebook)");
         SearchParams p;
         fill_search_params(p, a);
         p.mode = kModeFused;
@@ -1231,6 +1320,36 @@ int vq_quantize_f32(const vq_args *a, void *stream) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
     }
+    return 0;
+}
+
+int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs, int64_t idx_hs,
+                          const uint8_t *mask, int H, int64_t M, int K, int D, float *counts, float *sums, void *stream) {
+    if (H <= 0 || M < 0 || K <= 0 || D <= 0 || !counts || !sums) return fail(VQ_E_BADARG, "vq_ema_accumulate: bad argument");
+    if (M == 0) return 0;
+    if (!x || !idx) return fail(VQ_E_BADARG, "vq_ema_accumulate: null input");
+    long long blocks = (M + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vq_ema_accumulate_kernel, dim3((unsigned)blocks, (unsigned)H), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)x_rs, (long long)x_hs, (const long long *)idx, (long long)idx_rs, (long long)idx_hs, mask,
+                       (long long)M, K, D, counts, sums);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_ema_accumulate launch");
+    return 0;
+}
+
+int vq_ema_update_f32(float *cluster_size, float *embed_avg, float *embeddings, const float *counts, const float *sums,
+                      float *total_scratch, int H, int K, int D, float decay, float eps, int l2norm, void *stream) {
+    if (!cluster_size || !embed_avg || !embeddings || !counts || !sums || !total_scratch || H <= 0 || K <= 0 || D <= 0)
+        return fail(VQ_E_BADARG, "vq_ema_update: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    const float weight = 1.0f - decay;
+    hipLaunchKernelGGL(vq_ema_sizes_kernel, dim3(H), dim3(256), 0, s, cluster_size, counts, K, weight, total_scratch);
+    const long long rows = (long long)H * K;
+    hipLaunchKernelGGL(vq_ema_codes_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, cluster_size, total_scratch,
+                       embed_avg, sums, embeddings, H, K, D, weight, eps, l2norm);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_ema_update launch");
     return 0;
 }
 

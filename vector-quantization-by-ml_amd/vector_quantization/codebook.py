@@ -198,23 +198,34 @@ class Codebook(nn.Module):
         expressed with index arithmetic instead of the reference's [h, M, K] one-hot products."""
         h, m, d = flat.shape
         k = self.codebook_size
-        weights = torch.ones((h, m), dtype=flat.dtype, device=flat.device)
-        if flat_mask is not None:
-            weights = weights * flat_mask.to(flat.dtype)
-        hits = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
-        hits.scatter_add_(1, idx, weights)
-        self._sync_sum(hits)
-        self.cluster_size.data.lerp_(hits, 1.0 - self.decay)
+        if flat.is_cuda:
+            # native: scatter-add with float atomics, then one fused lerp / smoothing / normalise pass
+            from . import native
 
-        sums = torch.zeros((h, k, d), dtype=flat.dtype, device=flat.device)
-        sums.scatter_add_(1, idx[..., None].expand(h, m, d), flat * weights[..., None])
-        self._sync_sum(sums)
-        self.embed_avg.data.lerp_(sums, 1.0 - self.decay)
+            hits, sums = native.ema_accumulate(flat, idx, k, flat_mask)
+            self._sync_sum(hits)
+            self._sync_sum(sums)
+            codes = self.embeddings.data
+            native.ema_update(self.cluster_size.data, self.embed_avg.data, codes, hits, sums, self.decay,
+                              self.eps_for_smoothing, self.weights_regularization is _unit_rows)
+        else:  # host tensors only occur under the tests' checker backend
+            weights = torch.ones((h, m), dtype=flat.dtype, device=flat.device)
+            if flat_mask is not None:
+                weights = weights * flat_mask.to(flat.dtype)
+            hits = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
+            hits.scatter_add_(1, idx, weights)
+            self._sync_sum(hits)
+            self.cluster_size.data.lerp_(hits, 1.0 - self.decay)
 
-        total = self.cluster_size.sum(dim=-1, keepdim=True)
-        smoothed = (self.cluster_size + self.eps_for_smoothing) / (total + k * self.eps_for_smoothing) * total
-        fresh = self.weights_regularization(self.embed_avg / smoothed[..., None])
-        self.embeddings.data.copy_(fresh)
+            sums = torch.zeros((h, k, d), dtype=flat.dtype, device=flat.device)
+            sums.scatter_add_(1, idx[..., None].expand(h, m, d), flat * weights[..., None])
+            self._sync_sum(sums)
+            self.embed_avg.data.lerp_(sums, 1.0 - self.decay)
+
+            total = self.cluster_size.sum(dim=-1, keepdim=True)
+            smoothed = (self.cluster_size + self.eps_for_smoothing) / (total + k * self.eps_for_smoothing) * total
+            fresh = self.weights_regularization(self.embed_avg / smoothed[..., None])
+            self.embeddings.data.copy_(fresh)
         self.reseed_dead_codes(flat)
 
     @torch.no_grad()

@@ -88,6 +88,12 @@ def load():
         lib.vq_search_keys_f32.restype = ctypes.c_int
         lib.vq_finalize_keys_f32.argtypes = [ap, _vp, _vp]
         lib.vq_finalize_keys_f32.restype = ctypes.c_int
+        lib.vq_ema_accumulate_f32.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _vp, ctypes.c_int, _i64, ctypes.c_int,
+                                              ctypes.c_int, _vp, _vp, _vp]
+        lib.vq_ema_accumulate_f32.restype = ctypes.c_int
+        lib.vq_ema_update_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_float, ctypes.c_float, ctypes.c_int, _vp]
+        lib.vq_ema_update_f32.restype = ctypes.c_int
         lib.vq_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         lib.vq_device_info.restype = ctypes.c_int
         _lib = lib
@@ -97,7 +103,7 @@ def load():
 EXPORTED_SYMBOLS = (
     "vq_packed_floats", "vq_pack_codebooks_f32", "vq_workspace_bytes", "vq_quantize_f32", "vq_nearest_f32",
     "vq_residual_f32", "vq_keys_init", "vq_search_keys_f32", "vq_finalize_keys_f32", "vq_last_error",
-    "vq_device_info",
+    "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32",
 )
 
 
@@ -274,3 +280,38 @@ def finalize_keys(x: torch.Tensor, cb_full: torch.Tensor, keys: torch.Tensor, *,
     with torch.cuda.device(dev):
         _check(load().vq_finalize_keys_f32(ctypes.byref(a), keys.data_ptr(), _stream_ptr(dev)), "vq_finalize_keys_f32")
     return dict(out=out, idx=idx, best=best, sq_err=sq_err)
+
+
+def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, K: int, mask: torch.Tensor | None = None):
+    """x [H, M, D] (strided rows ok), idx [H, M] int64 (any strides) -> (counts [H, K], sums [H, K, D]) fp32."""
+    _require_gpu(x, idx)
+    assert x.dtype == torch.float32 and idx.dtype == torch.int64 and x.dim() == 3 and idx.dim() == 2
+    H, M, D = x.shape
+    dev = x.device
+    counts = torch.zeros((H, K), dtype=torch.float32, device=dev)
+    sums = torch.zeros((H, K, D), dtype=torch.float32, device=dev)
+    x_rs, x_hs = _row_strides(x)
+    m8 = None
+    if mask is not None:
+        m8 = mask.to(torch.uint8).contiguous()
+        assert tuple(m8.shape) == (H, M)
+    with torch.cuda.device(dev):
+        _check(load().vq_ema_accumulate_f32(x.data_ptr(), x_rs, x_hs, idx.data_ptr(), int(idx.stride(1)), int(idx.stride(0)),
+                                            m8.data_ptr() if m8 is not None else None, H, M, K, D, counts.data_ptr(),
+                                            sums.data_ptr(), _stream_ptr(dev)), "vq_ema_accumulate_f32")
+    return counts, sums
+
+
+def ema_update(cluster_size: torch.Tensor, embed_avg: torch.Tensor, embeddings: torch.Tensor, counts: torch.Tensor,
+               sums: torch.Tensor, decay: float, eps: float, l2norm: bool):
+    """In-place EMA step on the module buffers ([H, K], [H, K, D], [H, K, D]; contiguous fp32)."""
+    _require_gpu(cluster_size, embed_avg, embeddings, counts, sums)
+    for t in (cluster_size, embed_avg, embeddings, counts, sums):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    H, K, D = embed_avg.shape
+    dev = embed_avg.device
+    total = torch.empty((H,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(load().vq_ema_update_f32(cluster_size.data_ptr(), embed_avg.data_ptr(), embeddings.data_ptr(),
+                                        counts.data_ptr(), sums.data_ptr(), total.data_ptr(), H, K, D, float(decay),
+                                        float(eps), 1 if l2norm else 0, _stream_ptr(dev)), "vq_ema_update_f32")

@@ -30,16 +30,20 @@ class _NativeShardOps:
     """The three device steps, through the C ABI."""
 
     @staticmethod
-    def local_keys(x, shard, metric, idx_offset):
+    def prepare(shard, metric):
+        """Pack the (static) shard once: the codebook of a ShardedCodebookSearch does not change between calls."""
+        return native.pack_codebooks(shard[None].contiguous(), metric)
+
+    @staticmethod
+    def local_keys(x, shard, metric, idx_offset, packed=None):
         keys = torch.empty((1, x.shape[0]), dtype=torch.int64, device=x.device)
         native.keys_init(keys)
-        native.search_keys(x[None], shard[None].contiguous(), keys, metric=metric, idx_offset=idx_offset)
+        native.search_keys(x[None], shard[None], keys, metric=metric, idx_offset=idx_offset, packed=packed)
         return keys[0]
 
     @staticmethod
     def finalize(x, table, keys, metric, ste, want_sq_err):
-        r = native.finalize_keys(x[None], table[None].contiguous(), keys[None].contiguous(), metric=metric, ste=ste,
-                                 want_sq_err=want_sq_err)
+        r = native.finalize_keys(x[None], table[None], keys[None], metric=metric, ste=ste, want_sq_err=want_sq_err)
         return r["out"][0], r["idx"][0], r["best"][0], (r["sq_err"] if want_sq_err else None)
 
     @staticmethod
@@ -64,12 +68,16 @@ class ShardedCodebookSearch:
         self.shard = shard.contiguous().float()
         self.k_local = shard.shape[0]
         self.k_total = self.k_local * self.world
-        self.full = full_codebook
+        self.full = full_codebook.contiguous().float() if full_codebook is not None else None
         self.ops = ops if ops is not None else _NativeShardOps
+        self.packed = self.ops.prepare(self.shard, self.metric) if hasattr(self.ops, "prepare") else None
 
     def search_keys(self, x: torch.Tensor) -> torch.Tensor:
         """x [M, D] (identical on every rank) -> reduced keys [M] int64 (identical on every rank)."""
-        keys = self.ops.local_keys(x.float(), self.shard, self.metric, self.rank * self.k_local)
+        if self.packed is not None:
+            keys = self.ops.local_keys(x.float(), self.shard, self.metric, self.rank * self.k_local, self.packed)
+        else:
+            keys = self.ops.local_keys(x.float(), self.shard, self.metric, self.rank * self.k_local)
         if self.world > 1:
             dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
         return keys
