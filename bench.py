@@ -195,6 +195,33 @@ def cpu_baseline(w, budget_s):
                        f"(machine reports {os.cpu_count()} cpus)")
 
 
+def parity_gate(w, mod, x):
+    """Part of the cpu_baseline leg (rank 0, N = 1): the CPU oracle is the CHECKER for a sample of the GPU result."""
+    from oracle import vq_oracle
+
+    with torch.no_grad():
+        sample = x[:2]
+        out_s = mod(sample)
+    if w["kind"] == "vq" and w.get("heads", 1) == 1:
+        ref = vq_oracle.vq_forward(sample.reshape(1, -1, w["dim"]).cpu().numpy(), mod._codebook.embeddings.cpu().numpy())
+        ok = bool((out_s[1].reshape(-1).cpu().numpy() == ref["idx"][0]).all())
+        n_s = ref["idx"].size
+    elif w["kind"] == "rvq":
+        cbs = torch.stack([layer._codebook.embeddings[0] for layer in mod.layers]).cpu().numpy()
+        ref = vq_oracle.rvq_forward(sample.reshape(-1, w["dim"]).cpu().numpy(), cbs)
+        ok = bool((out_s[1].reshape(-1, w["Q"]).cpu().numpy() == ref["idx"]).all())
+        n_s = ref["idx"].size
+    else:
+        h, d = w["heads"], w["codebook_dim"]
+        flat = sample.reshape(-1, h, d).permute(1, 0, 2).contiguous().cpu().numpy()
+        ref = vq_oracle.vq_forward(flat, mod._codebook.embeddings.cpu().numpy())
+        ok = bool((out_s[1].reshape(-1, h).cpu().numpy() == ref["idx"].T).all())
+        n_s = ref["idx"].size
+    if not ok:
+        raise SystemExit("PARITY FAILURE: GPU indices differ from the CPU oracle; refusing to report a number")
+    return f"indices bit-exact vs CPU oracle on a {n_s}-index sample"
+
+
 def sharded_k65536(device, rank, world, steps=5):
     """BASELINE configs[4]: K=65536, D=512 sharded over the ranks, packed-key MIN all-reduce over RCCL."""
     from vector_quantization.sharded import ShardedCodebookSearch
@@ -265,32 +292,7 @@ def main():
     mod = build_module(w, device)
     x = torch.randn(w["x_shape"], generator=torch.Generator().manual_seed(1234 + rank)).to(device)
 
-    # ---- parity gate on a sample (rank 0): indices bit-exact vs the CPU oracle -------------------------------
     parity = None
-    if rank == 0:
-        from oracle import vq_oracle
-
-        with torch.no_grad():
-            sample = x[:2]
-            out_s = mod(sample)
-        if w["kind"] == "vq" and w.get("heads", 1) == 1:
-            ref = vq_oracle.vq_forward(sample.reshape(1, -1, w["dim"]).cpu().numpy(), mod._codebook.embeddings.cpu().numpy())
-            ok = bool((out_s[1].reshape(-1).cpu().numpy() == ref["idx"][0]).all())
-            n_s = ref["idx"].size
-        elif w["kind"] == "rvq":
-            cbs = torch.stack([layer._codebook.embeddings[0] for layer in mod.layers]).cpu().numpy()
-            ref = vq_oracle.rvq_forward(sample.reshape(-1, w["dim"]).cpu().numpy(), cbs)
-            ok = bool((out_s[1].reshape(-1, w["Q"]).cpu().numpy() == ref["idx"]).all())
-            n_s = ref["idx"].size
-        else:
-            h, d = w["heads"], w["codebook_dim"]
-            flat = sample.reshape(-1, h, d).permute(1, 0, 2).contiguous().cpu().numpy()
-            ref = vq_oracle.vq_forward(flat, mod._codebook.embeddings.cpu().numpy())
-            ok = bool((out_s[1].reshape(-1, h).cpu().numpy() == ref["idx"].T).all())
-            n_s = ref["idx"].size
-        if not ok:
-            raise SystemExit("PARITY FAILURE: GPU indices differ from the CPU oracle; refusing to report a number")
-        parity = f"indices bit-exact vs CPU oracle on a {n_s}-index sample"
 
     # ---- timed region ------------------------------------------------------------------------------------------
     with torch.no_grad():
@@ -327,6 +329,7 @@ def main():
             sharded = dict(error=str(e)[:200])
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        parity = parity_gate(w, mod, x)
         cpu = cpu_baseline(w, args.cpu_seconds)
 
     if rank == 0:

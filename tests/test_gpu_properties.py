@@ -178,3 +178,28 @@ def test_stream_reentrancy():
     torch.cuda.synchronize()
     assert torch.equal(r1["idx"], base["idx"]) and torch.equal(r2["idx"], base["idx"])
     assert torch.equal(r1["out"], base["out"]) and torch.equal(r2["best"], base["best"])
+
+
+def test_hip_graph_capture_and_replay(oracle):
+    """The launch functions allocate nothing and never synchronise, so a module forward can be captured into a
+    hipGraph (after one eager warm-up) and replayed on new data."""
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(0)
+    mod = vq.VectorQuantize(dim=64, codebook_params=CodebookParams(dim=64, codebook_size=256)).to(DEV).eval()
+    static_x = torch.randn(8, 128, 64, device=DEV)
+    with torch.no_grad():
+        mod(static_x)  # warm-up: attributes, device info
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            q, i, _ = mod(static_x)
+        for seed in (1, 2):
+            xn = _rand((8, 128, 64), seed)
+            static_x.copy_(xn.to(DEV))
+            g.replay()
+            torch.cuda.synchronize()
+            ri, _ = oracle.nearest(xn.reshape(-1, 64).numpy(), mod._codebook.embeddings[0].cpu().numpy(), oracle.EUCLID)
+            np.testing.assert_array_equal(i.reshape(-1).cpu().numpy(), ri)
+            assert torch.equal(q.reshape(-1, 64), mod._codebook.embeddings[0][i.reshape(-1)])

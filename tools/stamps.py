@@ -1,4 +1,8 @@
-"""Diagnostic: per-wave phase timestamps (needs lib/stamps.so built with -DVQ_EXP_STAMPS)."""
+"""Diagnostic: per-wave phase durations (prologue / sweep / finalize) from in-kernel s_memtime stamps.
+
+Build the diagnostic library first:  VQ_EXTRA_FLAGS=-DVQ_EXP_STAMPS ./build.sh && mv lib/libvq_mi355x.so lib/stamps.so
+then run with VQ_MI355X_LIB=.../lib/stamps.so python tools/stamps.py M,K,D
+"""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vector-quantization-by-ml_amd")]
@@ -25,13 +29,3 @@ for name, a in (("prologue", pro), ("sweep", sweep), ("finalize", fin), ("total"
 t0 = st[:, 0].min()
 print("kernel span cycles (memtime ticks):", st[:, 3].max() - t0)
 print("start-time spread of first-round waves:", np.percentile(st[:, 0] - t0, [0, 25, 50, 75, 100]))
-buf2 = (ctypes.c_uint64 * (8192 * 8))()
-lib.vq_debug_read_segs.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-lib.vq_debug_read_segs(buf2, 8192 * 8)
-sg = np.frombuffer(buf2, dtype=np.uint64).reshape(8192, 8).astype(np.float64)[:nw]
-ntile = (K + 31) // 32
-names = ["(7->0) loop/prefetch addr", "mfma g0 (4)", "epilogue(prev)", "mfma g1-2 (8)", "stage issue", "mfma g3.. (116)", "aug mfma", "barrier wait"]
-tot = sg[:, 1:].sum(1).mean() + sg[:, 0].mean()
-for i, nme in enumerate(names):
-    print(f"  seg{i} {nme:28s}: {sg[:, i].mean() / ntile:9.0f} cycles/tile  ({100 * sg[:, i].mean() / tot:5.1f} %)")
-print("  sum per tile:", tot / ntile)

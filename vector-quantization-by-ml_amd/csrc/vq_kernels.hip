@@ -178,7 +178,6 @@ __device__ __forceinline__ void glds16(const float *g, lds_f32x4 *l) {
 
 #ifdef VQ_EXP_STAMPS
 __device__ unsigned long long g_stamps[8192 * 4];
-__device__ unsigned long long g_segs[8192 * 8];
 #define STAMP(i) do { if (lane == 0) g_stamps[(((long long)blockIdx.x * WAVES + wave) & 8191) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(i) do { } while (0)
@@ -467,81 +466,34 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
         // MFMA drain) and the NEXT tile's LDS-DMA issue are expanded between MFMA groups, where they issue while
         // the matrix pipe is busy with this sub-tile.  `u` counts 32-code sub-tiles from code 0.
         constexpr int SUB = G::SUB;
-        // Roles of the two waves that share a SIMD (8-wave workgroups).  A dependent v_mfma_f32_32x32x2_f32 chain
-        // saturates the matrix pipe by itself, and the SIMD arbitrates by priority then age, so the two waves do
-        // not interleave: one streams its Dp/2 MFMAs, then the other.  Group A (waves 0..3, raised priority) streams
-        // FIRST and does its bookkeeping (this sub-tile's reduction, its share of the next tile's LDS-DMA) at the
-        // END, under B's stream; group B (waves 4..7) does its bookkeeping (previous sub-tile's reduction, DMA
-        // share) FIRST, under A's stream, then streams.  4-wave workgroups keep the interleaved form.
-#ifndef VQ_ROLES
-#define VQ_ROLES 0
-#endif
-        constexpr bool ROLES = (WAVES == 8) && VQ_ROLES;
-        const bool grp_b = ROLES && (wave >= WAVES / 2);
-#ifdef VQ_EXP_STAMPS
-#define EV(k) do { if (blockIdx.x == 300 && lane == 0 && u >= 100 && u < 104) { unsigned long long tn_; \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_) :: "memory"); \
-        g_segs[(wave * 4 + (u - 100)) * 8 + (k)] = tn_; } } while (0)
-#else
-#define EV(k) do { } while (0)
-#endif
+        // One 32-code sub-tile: Dp/2 MFMAs into `acc`, then the augmented-column MFMA (|x|^2 * 1 + 1 * |c|^2).
+        // Software pipelined inside the wave: the PREVIOUS sub-tile's reduction (`prev`, finished long ago, so no
+        // MFMA drain) and the NEXT tile's LDS-DMA issue are expanded between MFMA groups.  `u` counts 32-code
+        // sub-tiles from code 0.  (Measured alternatives -- explicit wave roles, half-tile stagger -- are slower:
+        // f32 MFMA runs on the SIMD's FMA lanes, so a streaming wave starves its SIMD partner; see DESIGN.md.)
         auto run_sub = [&](f32x16 &acc, f32x16 &prev, int u, bool have_prev) {
             const int t = u / SUB, st = u % SUB;
             const int cur = (t - t0) & 1;
             const f32x4 *tb = tile4 + cur * G::BUF_F4 + st * (kTileCodes * RS4);
             constexpr int NG = DP / 8;
+            constexpr int G1 = NG >= 2 ? 1 : NG, G2 = NG >= 4 ? 3 : NG;
             const f32x4 *ta = tb + c * RS4 + h;
             f32x4 a[NG];
             acc = (f32x16){0};
-            EV(0);
-            if (ROLES) {
-                if (grp_b) {
-                    if (have_prev) tile_epilogue<METRIC, DP>(prev, u - 1, h, p.K, best_t, best_s, best_i);
-                    EV(1);
-                    if (st == 0 && t + 1 < t1) stage(t + 1, cur ^ 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    EV(2);
-                } else {
-#if VQ_ROLES == 2
-                    __builtin_amdgcn_s_setprio(1);
-#endif
-                }
-                mfma_prefetch<DP>(a, ta);
-                mfma_range<DP, 0, 1>(acc, a, ta, xf);
-                EV(3);
-                mfma_range<DP, 1, NG>(acc, a, ta, xf);
-                EV(4);
-            } else {
-                constexpr int G1 = NG >= 2 ? 1 : NG, G2 = NG >= 4 ? 3 : NG;
-                mfma_prefetch<DP>(a, ta);
-                mfma_range<DP, 0, G1>(acc, a, ta, xf);
-                EV(1);
-                if (have_prev) tile_epilogue<METRIC, DP>(prev, u - 1, h, p.K, best_t, best_s, best_i);
-                __builtin_amdgcn_sched_barrier(0);
-                EV(2);
-                mfma_range<DP, G1, G2>(acc, a, ta, xf);
-                EV(3);
-                if (st == 0 && t + 1 < t1) stage(t + 1, cur ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-                EV(4);
-                mfma_range<DP, G2, NG>(acc, a, ta, xf);
-            }
-            EV(5);
+            mfma_prefetch<DP>(a, ta);
+            mfma_range<DP, 0, G1>(acc, a, ta, xf);
+            if (have_prev) tile_epilogue<METRIC, DP>(prev, u - 1, h, p.K, best_t, best_s, best_i);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_range<DP, G1, G2>(acc, a, ta, xf);
+            if (st == 0 && t + 1 < t1) stage(t + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_range<DP, G2, NG>(acc, a, ta, xf);
             if (EUCLID) {
                 const float cnv = ((const float *)tb)[c * RS + DP];
                 const float a_aug = h ? cnv : 1.0f;  // A[code][k=0] = 1, A[code][k=1] = |c|^2
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, acc, 0, 0, 0);
             }
-            if (ROLES && !grp_b) {
-#if VQ_ROLES == 2
-                __builtin_amdgcn_s_setprio(0);
-#endif
-                if (st == 0 && t + 1 < t1) stage(t + 1, cur ^ 1);
-                tile_epilogue<METRIC, DP>(acc, u, h, p.K, best_t, best_s, best_i);
-            }
-            EV(6);
             if (st == SUB - 1) __syncthreads();  // next tile landed (vmcnt(0)), everybody is done reading this one
-            EV(7);
         };
 
         stage(t0, 0);
@@ -556,12 +508,11 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
                 run_sub(acc1, acc0, u + 1, true);
                 have_prev = true;
             }
-            const bool pipelined = !ROLES || grp_b;  // group A reduces every sub-tile in place
             if (u < u1) {
                 run_sub(acc0, acc1, u, have_prev);
-                if (pipelined) tile_epilogue<METRIC, DP>(acc0, u, h, p.K, best_t, best_s, best_i);
+                tile_epilogue<METRIC, DP>(acc0, u, h, p.K, best_t, best_s, best_i);
             } else if (have_prev) {
-                if (pipelined) tile_epilogue<METRIC, DP>(acc1, u - 1, h, p.K, best_t, best_s, best_i);
+                tile_epilogue<METRIC, DP>(acc1, u - 1, h, p.K, best_t, best_s, best_i);
             }
         }
 
@@ -1160,9 +1111,6 @@ const char *vq_last_error(void) { return g_err; }
 int vq_debug_read_stamps(unsigned long long *host, size_t n) {  // diagnostic build only
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long));
 }
-int vq_debug_read_segs(unsigned long long *host, size_t n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_segs), n * sizeof(unsigned long long));
-}
 #endif
 
 int vq_device_info(char *buf, size_t n) {
@@ -1272,9 +1220,6 @@ int vq_quantize_f32(const vq_args *a, void *stream) {
     // ---- choose fused (one launch, no K split) or split (keys + finalize) ----
     bool fused = !simple;
     int waves = (DP == 512) ? 4 : 8;
-    if (const char *ev = getenv("VQ_WAVES")) {
-        if (atoi(ev) == 4) waves = 4;
-    }
     if (fused) {
         long long wgs = (long long)a->H * ((a->M + 32 * waves - 1) / (32 * waves));
         if (waves == 8 && wgs < cus) {
