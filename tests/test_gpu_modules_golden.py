@@ -135,3 +135,70 @@ def test_kmeans_init_runs_on_native_search():
     assert q.shape == x.shape and idx.shape == x.shape[:-1]
     assert mod._codebook.is_initialized
     assert float(mod._codebook.cluster_size.sum()) > 0
+
+
+def test_learnable_codebook_gradients_match_torch_formulation():
+    """learnable_codebook (no EMA): the codebook receives the commitment-loss gradient through the gathered rows
+    (reference: one-hot einsum + mse_loss(quantize, x), vector_quantize_pytorch.py:263-269,362)."""
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    K, D = 16, 8
+    mod = vq.VectorQuantize(dim=D, codebook_params=CodebookParams(dim=D, codebook_size=K, learnable_codebook=True,
+                                                                ema_update=False), commitment_weight=0.5).to(dev)
+    mod.train()
+    x = torch.randn(4, 9, D, device=dev, requires_grad=True)
+    q, idx, loss = mod(x)
+    loss.sum().backward()
+    codes = mod._codebook.embeddings.detach()[0]
+    sel = codes[idx]
+    n = x.numel()
+    # d/dx of w * mean((c - x)^2) and d/dc scattered onto the selected rows
+    torch.testing.assert_close(x.grad, 0.5 * 2.0 * (x.detach() - sel) / n, rtol=1e-5, atol=1e-7)
+    expect = torch.zeros_like(codes)
+    expect.index_add_(0, idx.reshape(-1), (0.5 * 2.0 * (sel - x.detach()) / n).reshape(-1, D))
+    torch.testing.assert_close(mod._codebook.embeddings.grad[0], expect, rtol=1e-5, atol=1e-7)
+
+
+def test_similarities_on_demand_and_codebook_forward_api():
+    from vector_quantization.codebooks import Codebook
+
+    torch.manual_seed(4)
+    dev = "cuda:0"
+    cb = Codebook(dim=16, codebook_size=32, num_codebooks=2).to(dev).eval()
+    x = torch.randn(2, 3, 11, 16, device=dev)  # [h, b, n, d]
+    q, ind, sims = cb(x, return_similarities=True)
+    assert q.shape == x.shape and ind.shape == (2, 3, 11) and sims.shape == (2, 3, 11, 32)
+    assert torch.equal(ind, sims.argmax(-1))
+    q2, ind2, none = cb(x)
+    assert none is None and torch.equal(ind2, ind) and torch.equal(q2, q)
+    x3 = torch.randn(3, 11, 16, device=dev)  # [b, n, d] with a single codebook
+    cb1 = Codebook(dim=16, codebook_size=32).to(dev).eval()
+    q3, ind3, _ = cb1(x3)
+    assert q3.shape == x3.shape and ind3.shape == (3, 11)
+
+
+def test_multihead_mask_train_matches_manual():
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(5)
+    dev = "cuda:0"
+    mod = vq.VectorQuantize(dim=32, heads=2, codebook_dim=16, separate_codebook_per_head=True,
+                            codebook_params=CodebookParams(dim=16, codebook_size=24)).to(dev).train()
+    x = torch.randn(3, 10, 32, device=dev)
+    mask = torch.zeros(3, 10, dtype=torch.bool, device=dev)
+    mask[0, :10] = True
+    mask[1, :4] = True
+    mask[2, :1] = True
+    with torch.no_grad():
+        q, idx, loss = mod(x, mask=mask, freeze_codebook=True)
+    codes = mod._codebook.embeddings
+    xh = x.view(3, 10, 2, 16)
+    sel = torch.stack([codes[h][idx[..., h]] for h in range(2)], dim=2)  # [b, n, h, d]
+    manual = ((sel - xh) ** 2)[mask].mean()
+    torch.testing.assert_close(loss[0], manual, rtol=1e-5, atol=1e-7)
+    assert torch.equal(q[~mask], x[~mask])
+    torch.testing.assert_close(q[mask], (xh + (sel - xh)).reshape(3, 10, 32)[mask], rtol=0, atol=1e-6)
