@@ -302,6 +302,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
+        native.begin_kernel_timing()  # HIP events around the search launch, on its own stream, inside the timed region
         t0 = time.perf_counter()
         for _ in range(args.steps):
             mod(x)
@@ -310,6 +311,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
         elapsed = time.perf_counter() - t0
+        kernel_events = native.end_kernel_timing()
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,6 +322,14 @@ def main():
     roof = None
     with torch.no_grad():
         roof = kernel_roofline(w, device, mod, x)
+    if kernel_events:
+        # the figure of record: mean duration of the search launch DURING the timed steps
+        live_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / len(kernel_events)
+        roof["kernel_ms_isolated"] = roof["kernel_ms"]
+        roof["kernel_ms"] = round(live_ms, 4)
+        roof["achieved"] = round(roof["algorithmic_flops_per_launch"] / (live_ms * 1e-3) / 1e12, 2)
+        roof["frac"] = round(roof["achieved"] / PEAK_F32_MFMA_TFLOPS, 4)
+        roof["launches_timed"] = len(kernel_events)
     sharded = None
     if not args.no_sharded:
         try:

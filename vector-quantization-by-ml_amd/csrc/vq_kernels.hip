@@ -253,13 +253,35 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
     return o;
 }
 
+// Per-lane running state of the argmin over the codes a lane has seen (16 per 32-code sub-tile, ascending).
+// `pend` parks the 16 values of the sub-tile that produced the current record low; the expensive part of the
+// tie-exact rule (correctly rounded sqrt, rounding-band threshold, lowest index inside the band) is resolved ONCE at
+// the end of the sweep instead of on every record (with 64 lanes x few tiles some lane sets a record on nearly every
+// tile, and on gfx950 those vector instructions are not hidden behind the f32 MFMA stream).
+struct LaneBest {
+    float best_t;   // Euclid: min clamped squared distance so far; dot: max similarity so far
+    int pend_u;     // sub-tile that produced it
+    f32x16 pend;    // its 16 values
+};
+
+__device__ __forceinline__ float rounding_band_hi(float sq) {
+    // largest fp32 t whose correctly rounded sqrt is still `sq`:  t < (sq + ulp(sq)/2)^2, exact in fp64
+    const float up = __uint_as_float(__float_as_uint(sq) + 1u);  // next float above (sq >= 0)
+    const double mid = (double)sq + 0.5 * ((double)up - (double)sq);
+    const double lim = mid * mid;
+    float hi = (float)lim;
+    if ((double)hi >= lim) hi = __uint_as_float(__float_as_uint(hi) - 1u);
+    return hi;
+}
+
+// End of a 32-code sub-tile for one wave: tail masking + in-lane reduction of the 32x32 result.
+// A lane holds 16 codes of ONE row: acc[r] <-> code u*32 + 4*h + (r&3) + 8*(r>>2), ascending in r.
 template <int METRIC, int DP>
-__device__ __forceinline__ void tile_epilogue(f32x16 &acc, int t, int h, int K, float &best_t, float &best_s,
-                                              int &best_i) {
+__device__ __forceinline__ void tile_epilogue(f32x16 &acc, int u, int h, int K, LaneBest &st) {
     const float INF = __builtin_inff();
-    const int cbase = t * kTileCodes + 4 * h;
+    const int cbase = u * kTileCodes + 4 * h;
     if (METRIC == VQ_METRIC_EUCLID) {
-        if (t * kTileCodes + kTileCodes > K) {
+        if (u * kTileCodes + kTileCodes > K) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (cbase + (r & 3) + 8 * (r >> 2) >= K) acc[r] = INF;
@@ -272,29 +294,20 @@ __device__ __forceinline__ void tile_epilogue(f32x16 &acc, int t, int h, int K, 
         tm = vmin3(tm, acc[11], acc[12]);
         tm = vmin3(tm, acc[13], acc[14]);
         tm = vmax3(fminf(tm, acc[15]), 0.0f, 0.0f);  // clamp_min_(0) commutes with min
-        if (tm < best_t) {
-            // A new record low of the (clamped) squared distance: only now can the argmin change.
-            // Closed form of the in-order scan: s = sqrt(tile min); if it beats the running best, the winner is
-            // the LOWEST code of this lane whose sqrt rounds to the same s, i.e. whose t < (s + ulp(s)/2)^2.  That
-            // bound is exact in fp64 (square of a 25-bit value); `hi` is the largest fp32 below it, so the per-code
-            // test is one fp32 compare on the UNclamped value (t < 0 clamps to 0 <= hi anyway).
-            best_t = tm;
-            const float sq = sqrtf(tm);  // correctly rounded
-            if (sq < best_s) {
-                best_s = sq;
-                const float up = __uint_as_float(__float_as_uint(sq) + 1u);  // next float above (sq >= 0)
-                const double mid = (double)sq + 0.5 * ((double)up - (double)sq);
-                const double lim = mid * mid;
-                float hi = (float)lim;
-                if ((double)hi >= lim) hi = __uint_as_float(__float_as_uint(hi) - 1u);  // lim > 0 always
-                int bi = 0;
-#pragma unroll
-                for (int r = 15; r >= 0; --r) bi = (acc[r] <= hi) ? (r & 3) + 8 * (r >> 2) : bi;
-                best_i = cbase + bi;
+        if (tm < st.best_t) {
+            // A new record low of the squared distance.  It replaces the parked sub-tile unless its sqrt ROUNDS to the
+            // same value as the parked minimum's (then the earlier sub-tile keeps the win: lower codes).  Two values
+            // more than 2^-21 apart (relative) cannot share a rounded sqrt, so only near-ties pay for the two sqrts.
+            bool take = true;
+            if (tm * 1.0000004768371582f >= st.best_t) take = sqrtf(tm) < sqrtf(st.best_t);
+            if (take) {
+                st.best_t = tm;
+                st.pend_u = u;
+                st.pend = acc;
             }
         }
     } else {
-        if (t * kTileCodes + kTileCodes > K) {
+        if (u * kTileCodes + kTileCodes > K) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (cbase + (r & 3) + 8 * (r >> 2) >= K) acc[r] = -INF;
@@ -307,14 +320,29 @@ __device__ __forceinline__ void tile_epilogue(f32x16 &acc, int t, int h, int K, 
         tm = vmax3(tm, acc[11], acc[12]);
         tm = vmax3(tm, acc[13], acc[14]);
         tm = vmax3(tm, acc[15], acc[15]);
-        if (tm > best_s) {  // strictly better than everything earlier: take the lowest code that attains it
-            best_s = tm;
-            int bi = 0;
-#pragma unroll
-            for (int r = 15; r >= 0; --r) bi = (acc[r] == tm) ? (r & 3) + 8 * (r >> 2) : bi;
-            best_i = cbase + bi;
+        if (tm > st.best_t) {  // strictly better than everything earlier
+            st.best_t = tm;
+            st.pend_u = u;
+            st.pend = acc;
         }
     }
+}
+
+// End of a sweep: turn the parked sub-tile into (value in the compared space, lowest winning code of this lane).
+template <int METRIC>
+__device__ __forceinline__ void resolve_best(const LaneBest &st, int h, float &best_s, int &best_i) {
+    int bi = 0;
+    if (METRIC == VQ_METRIC_EUCLID) {
+        best_s = sqrtf(st.best_t);  // correctly rounded; +inf if the lane saw no finite distance
+        const float hi = (st.best_t < __builtin_inff()) ? rounding_band_hi(best_s) : __builtin_inff();
+#pragma unroll
+        for (int r = 15; r >= 0; --r) bi = (st.pend[r] <= hi) ? (r & 3) + 8 * (r >> 2) : bi;  // unclamped: t < 0 -> 0 <= hi
+    } else {
+        best_s = st.best_t;
+#pragma unroll
+        for (int r = 15; r >= 0; --r) bi = (st.pend[r] == st.best_t) ? (r & 3) + 8 * (r >> 2) : bi;
+    }
+    best_i = st.pend_u * kTileCodes + 4 * h + bi;
 }
 
 template <int DP, int WAVES, int METRIC, bool MULTI>
@@ -442,9 +470,17 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
             b_aug = h ? 1.0f : xn;  // B[k=0][row] = |x|^2, B[k=1][row] = 1
         }
 
-        float best_t = INF;                  // Euclid: running min of the clamped squared distance
-        float best_s = EUCLID ? INF : -INF;  // running best value in the compared space
-        int best_i = 0;
+        LaneBest lb;
+        lb.best_t = EUCLID ? INF : -INF;
+        lb.pend_u = 0;
+        lb.pend = (f32x16){0};
+        if (EUCLID) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lb.pend[r] = INF;  // nothing parked yet (pend[0] <= +inf still selects code 0)
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lb.pend[r] = -INF;
+        }
 
         const int t0 = blockIdx.z * p.tiles_per_split;
         const int t1 = (t0 + p.tiles_per_split < p.ntiles) ? t0 + p.tiles_per_split : p.ntiles;
@@ -482,7 +518,7 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
             acc = (f32x16){0};
             mfma_prefetch<DP>(a, ta);
             mfma_range<DP, 0, G1>(acc, a, ta, xf);
-            if (have_prev) tile_epilogue<METRIC, DP>(prev, u - 1, h, p.K, best_t, best_s, best_i);
+            if (have_prev) tile_epilogue<METRIC, DP>(prev, u - 1, h, p.K, lb);
             __builtin_amdgcn_sched_barrier(0);
             mfma_range<DP, G1, G2>(acc, a, ta, xf);
             if (st == 0 && t + 1 < t1) stage(t + 1, cur ^ 1);
@@ -510,11 +546,15 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
             }
             if (u < u1) {
                 run_sub(acc0, acc1, u, have_prev);
-                tile_epilogue<METRIC, DP>(acc0, u, h, p.K, best_t, best_s, best_i);
+                tile_epilogue<METRIC, DP>(acc0, u, h, p.K, lb);
             } else if (have_prev) {
-                tile_epilogue<METRIC, DP>(acc1, u - 1, h, p.K, best_t, best_s, best_i);
+                tile_epilogue<METRIC, DP>(acc1, u - 1, h, p.K, lb);
             }
         }
+
+        float best_s;
+        int best_i;
+        resolve_best<METRIC>(lb, h, best_s, best_i);
 
         // merge the two lane halves of each row (they saw disjoint codes)
         {

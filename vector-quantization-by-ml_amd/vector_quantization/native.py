@@ -48,6 +48,24 @@ class NativeUnavailable(RuntimeError):
     pass
 
 
+# Optional measurement hook (bench.py): when enabled, every vq_quantize_f32 launch is bracketed by HIP events
+# recorded on the SAME stream the kernel is enqueued on, so the kernel's duration can be read back after the
+# timed region without a profiler.  Off by default (two event records cost a few microseconds of host time).
+_event_sink = None
+
+
+def begin_kernel_timing():
+    global _event_sink
+    _event_sink = []
+
+
+def end_kernel_timing():
+    """-> list of (start_event, end_event); call torch.cuda.synchronize() before reading elapsed times."""
+    global _event_sink
+    events, _event_sink = _event_sink, None
+    return events or []
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -219,7 +237,13 @@ def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bo
     a.sq_err = sq_err.data_ptr() if sq_err is not None else None
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8
     with torch.cuda.device(dev):
+        if _event_sink is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
         _check(load().vq_quantize_f32(ctypes.byref(a), _stream_ptr(dev)), "vq_quantize_f32")
+        if _event_sink is not None:
+            e1.record(torch.cuda.current_stream(dev))
+            _event_sink.append((e0, e1))
     return dict(out=out, idx=idx, best=best, sq_err=sq_err)
 
 
