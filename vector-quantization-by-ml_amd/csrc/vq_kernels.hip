@@ -516,6 +516,8 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
             const f32x4 *ta = tb + c * RS4 + h;
             f32x4 a[NG];
             acc = (f32x16){0};
+            // |c|^2 of this lane's code for the augmented MFMA: read now so its LDS latency is not paid at the tail
+            const float cnv = EUCLID ? ((const float *)tb)[c * RS + DP] : 0.0f;
             mfma_prefetch<DP>(a, ta);
             mfma_range<DP, 0, G1>(acc, a, ta, xf);
             if (have_prev) tile_epilogue<METRIC, DP>(prev, u - 1, h, p.K, lb);
@@ -525,7 +527,6 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
             __builtin_amdgcn_sched_barrier(0);
             mfma_range<DP, G2, NG>(acc, a, ta, xf);
             if (EUCLID) {
-                const float cnv = ((const float *)tb)[c * RS + DP];
                 const float a_aug = h ? cnv : 1.0f;  // A[code][k=0] = 1, A[code][k=1] = |c|^2
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, acc, 0, 0, 0);
             }
