@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
                 const float *src = xh + grow * p.x_rs + d0;
                 f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (p.vec_x) {
-                    if (d0 < p.D) t = *(const f32x4 *)src;
+                    if (d0 < p.D) t = __builtin_nontemporal_load((const f32x4 *)src);  // each row is read once
                 } else {
                     if (d0 + 0 < p.D) t.x = src[0];
                     if (d0 + 1 < p.D) t.y = src[1];
@@ -691,7 +691,7 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
 #pragma unroll
                     for (int j = 0; j < G::NCH4; ++j) {
                         const int d = 4 * (lane + 64 * j);
-                        if (d < p.D) *(f32x4 *)(orow + d) = o[k][j];
+                        if (d < p.D) __builtin_nontemporal_store(o[k][j], (f32x4 *)(orow + d));  // streamed once, never re-read
                     }
                 }
             }
