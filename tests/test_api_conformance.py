@@ -191,3 +191,25 @@ def test_import_surface():
     p = CodebookParams(dim=4, codebook_size=8)
     assert (p.decay, p.ema_update, p.threshold_ema_dead_code, p.use_cosine_sim) == (0.8, True, 2, False)
     assert vector_quantization.__all__
+
+
+def test_random_projection_quantizer(device):
+    """Repaired BEST-RQ quantizer: indices equal a manual LayerNorm -> projection -> cosine argmax."""
+    import vector_quantization as vq
+
+    torch.manual_seed(0)
+    mod = vq.RandomProjectionQuantizer(dim=24, codebook_size=40, codebook_dim=8, num_codebooks=3).to(device)
+    x = torch.randn(2, 30, 24, device=device)
+    idx = mod(x)
+    assert idx.shape == (2, 30, 3) and idx.dtype == torch.int64
+    xn = torch.nn.functional.layer_norm(x, (24,))
+    proj = torch.einsum("bnd,hde->bnhe", xn, mod.rand_projs)
+    proj = torch.nn.functional.normalize(proj, dim=-1)
+    codes = mod.vq._codebook.embeddings  # [h, K, e], l2-normalised at construction
+    torch.testing.assert_close(codes.norm(dim=-1), torch.ones_like(codes[..., 0]), rtol=1e-5, atol=1e-5)
+    sims = torch.einsum("bnhe,hke->bnhk", proj, codes)
+    manual = sims.argmax(-1)
+    agree = (manual == idx).float().mean().item()
+    assert agree > 0.99, agree  # fp32 summation order may flip exact near-ties only
+    picked = torch.gather(sims, -1, idx[..., None])[..., 0]
+    torch.testing.assert_close(picked, sims.max(-1).values, rtol=0, atol=1e-5)

@@ -12,6 +12,7 @@ touch the codebook search and are not part of this build.
 """
 from .codebook import Codebook
 from .params import AffineParameters, CodebookParams, GumbelParams, KmeansParameters
+from .projection import RandomProjectionQuantizer
 from .quantizer import LossBreakdown, VectorQuantize
 from .residual import GroupedResidualVQ, ResidualVQ
 from .sharded import ShardedCodebookSearch
@@ -24,6 +25,7 @@ __all__ = [
     "GumbelParams",
     "KmeansParameters",
     "LossBreakdown",
+    "RandomProjectionQuantizer",
     "ResidualVQ",
     "ShardedCodebookSearch",
     "VectorQuantize",

