@@ -4,12 +4,13 @@
 //   pack      natural codebook [K, D]  ->  packed image  [Kp][Dp + 4]  (even/odd de-interleave inside
 //             each group of 8 dims, pre-scaled by -2 for Euclid, |c|^2 in float Dp of every row)
 //   search    one wave owns 32 rows of x for the whole sweep; their fp32 values live in REGISTERS as
-//             v_mfma_f32_32x32x2_f32 B-fragments (Dp/2 VGPRs per lane).  The workgroup streams 32-code
-//             tiles of the packed image HBM/L2 -> LDS with global_load_lds (double buffered) and each
-//             wave runs Dp/2 MFMAs per tile (codes on the MFMA i axis, rows on the j axis), then ONE
-//             more MFMA that adds |x|^2 * 1 + 1 * |c|^2  (the two augmented GEMM columns of ATen's
-//             cdist).  The 32x32 result tile is reduced in-lane (a lane holds 16 codes of ONE row),
-//             sqrt only on new record lows, lowest index on ties.
+//             v_mfma_f32_32x32x2_f32 B-fragments (Dp/2 VGPRs per lane).  The workgroup streams ~33 KB
+//             tiles of the packed image HBM/L2 -> LDS with buffer_load ... lds (LDS-DMA, double
+//             buffered) and each wave runs Dp/2 MFMAs per 32-code sub-tile (codes on the MFMA i axis,
+//             rows on the j axis), then ONE more MFMA that adds |x|^2 * 1 + 1 * |c|^2  (the two
+//             augmented GEMM columns of ATen's cdist).  The 32x32 result is reduced in-lane (a lane holds
+//             16 codes of ONE row): min3 tree per sub-tile, the record sub-tile's values are parked and
+//             the tie-exact rule (correctly rounded sqrt, lowest index) is resolved once per sweep.
 //   finalize  gather codebook[idx] (natural layout), straight-through, squared-error sums; fused in
 //             the search kernel unless the sweep was split over K (packed 64-bit keys + atomic min).
 //
@@ -170,11 +171,6 @@ struct SearchParams {
 
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
 
-// LDS-DMA: 16 B per lane, LDS destination = wave-uniform base + lane * 16 (no VGPR round trip)
-__device__ __forceinline__ void glds16(const float *g, lds_f32x4 *l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)l, 16, 0, 0);
-}
 
 #ifdef VQ_EXP_STAMPS
 __device__ unsigned long long g_stamps[8192 * 4];
