@@ -223,3 +223,24 @@ def test_near_tie_heavy_default_init_large(oracle, M, K, D):
     sims = oracle.similarities(x[0, :512].numpy(), cb[0].numpy(), oracle.EUCLID)
     top2 = np.sort(-sims, axis=1)[:, :2]
     assert (top2[:, 0] == top2[:, 1]).mean() > 0.005
+
+
+def test_integration_md_stub_runs_as_written(oracle):
+    """The ctypes stub printed in INTEGRATION.md (what a maintainer of the reference would add) is executed verbatim."""
+    import os
+    import re
+
+    native = _native()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n# vector_quantization/_mi355x.py.*?\n(.*?)```", text, flags=re.S).group(1)
+    code = code.replace('ctypes.CDLL("libvq_mi355x.so")', f'ctypes.CDLL("{native.lib_path()}")')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    x = _rand((2, 700, 48), 21)
+    cb = _rand((2, 130, 48), 22)
+    out, idx = ns["nearest"](x.to(DEV), cb.to(DEV))
+    torch.cuda.synchronize()
+    ref = oracle.vq_forward(x.numpy(), cb.numpy(), oracle.EUCLID)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref["idx"])
+    np.testing.assert_array_equal(out.cpu().numpy(), ref["out"])
