@@ -133,6 +133,21 @@ int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int6
 int vq_ema_update_f32(float *cluster_size, float *embed_avg, float *embeddings, const float *counts, const float *sums,
                       float *total_scratch, int H, int K, int D, float decay, float eps, int l2norm, void *stream);
 
+/*
+ * Consumers of the similarity matrix.  Both use a->x, a->packed (a->cb for D > 512 / VQ_F_FORCE_SIMPLE),
+ * H, M, K, D, metric; Q is ignored.
+ * vq_similarities_f32: sims[h*sims_hs + m*sims_rs + k] = -cdist(x, c) (Euclid) or x.c (dot): the third return value of
+ *   Codebook.forward -- codebooks.py:386,435 -- bit-identical to the values the search compares.  The caller chooses
+ *   how many rows to materialise at once (row chunks via the x / sims pointers).
+ * vq_softmax_stats_f32: logits = scale * similarity; lse[h*M + m] = log sum_k exp(logit), target_logit[h*M + m] = logit
+ *   of code target[h*tgt_hs + m*tgt_rs] (0 for a negative = ignored target; -inf for one >= K).  This is
+ *   F.cross_entropy(distances, codes, ignore_index=-1) -- vector_quantize_pytorch.py:287-297 -- as an online-softmax
+ *   epilogue of the sweep: [M, K] never exists.  target may be NULL (lse only).  Accuracy: native sqrt/exp/log (1e-6 rel).
+ */
+int vq_similarities_f32(const vq_args *a, float *sims, int64_t sims_rs, int64_t sims_hs, void *stream);
+int vq_softmax_stats_f32(const vq_args *a, float scale, const int64_t *target, int64_t tgt_rs, int64_t tgt_hs, float *lse,
+                         float *target_logit, void *stream);
+
 const char *vq_last_error(void);
 int vq_device_info(char *buf, size_t n); /* "gfx950 ... CUs" of the current device */
 

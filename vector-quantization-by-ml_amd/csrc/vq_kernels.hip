@@ -752,6 +752,262 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_search_mfm
 }
 
 // ------------------------------------------------------------------------------------------------
+// similarity consumers: the same MFMA sweep with two other epilogues.
+//   kAuxSims   write sim[h, m, k] = -sqrt(max(0, t)) (Euclid) / x.c (dot) -- the third return value of
+//              Codebook.forward (codebooks.py:386,435), bit-identical to the values the search compares.
+//   kAuxStats  online softmax over logits = scale * sim: per row log-sum-exp and the logit of a given target code
+//              (F.cross_entropy(distances, codes) -- vector_quantize_pytorch.py:287-297 -- without [M, K] in memory).
+// Performance is secondary here (training-only losses): plain loop, no in-wave software pipeline.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAuxSims = 0;
+constexpr int kAuxStats = 1;
+
+struct AuxParams {
+    const float *x;
+    long long x_rs, x_hs;
+    const float *packed;
+    long long pk_hs;
+    unsigned pk_bytes;
+    long long M;
+    int K, D, ntiles, vec_x;
+    float *sims;  // kAuxSims
+    long long sims_rs, sims_hs;
+    int vec_s;
+    float scale;  // kAuxStats
+    const long long *target;
+    long long tgt_rs, tgt_hs;
+    float *lse, *tgt_logit;  // [H * M]
+};
+
+// x rows of one wave -> MFMA B fragments (same layout and |x|^2 chain as the search kernel's prologue)
+template <int DP, int WAVES, bool EUCLID>
+__device__ __forceinline__ void load_x_fragments(const float *xh, long long x_rs, long long M, int D, int vec_x,
+                                                 long long row0, float *smem, int wave, int lane,
+                                                 float (&xf)[DP / 2], float &xn0) {
+    using G = Geo<DP, WAVES>;
+    constexpr int CH = G::CH, XS = G::XS;
+    const int c = lane & 31, h = lane >> 5;
+    float *xs = smem + wave * (32 * XS);
+    constexpr int NCHUNK = DP / CH;
+    constexpr int LPL = CH / 8;
+    xn0 = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+#pragma unroll
+        for (int it = 0; it < LPL; ++it) {
+            const int f = it * 64 + lane;
+            const int r = f / (CH / 4), c4 = f % (CH / 4);
+            long long grow = row0 + r;
+            if (grow >= M) grow = M - 1;
+            const int d0 = ch * CH + c4 * 4;
+            const float *src = xh + grow * x_rs + d0;
+            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (vec_x) {
+                if (d0 < D) t = *(const f32x4 *)src;
+            } else {
+                if (d0 + 0 < D) t.x = src[0];
+                if (d0 + 1 < D) t.y = src[1];
+                if (d0 + 2 < D) t.z = src[2];
+                if (d0 + 3 < D) t.w = src[3];
+            }
+            *(f32x4 *)(xs + r * XS + c4 * 4) = t;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const float *rp = xs + c * XS;
+#pragma unroll
+        for (int j = 0; j < CH / 8; ++j) {
+            const f32x4 lo = *(const f32x4 *)(rp + 8 * j);
+            const f32x4 hi = *(const f32x4 *)(rp + 8 * j + 4);
+            if (EUCLID) {
+                xn0 = fmaf(lo.x, lo.x, xn0);
+                xn0 = fmaf(lo.y, lo.y, xn0);
+                xn0 = fmaf(lo.z, lo.z, xn0);
+                xn0 = fmaf(lo.w, lo.w, xn0);
+                xn0 = fmaf(hi.x, hi.x, xn0);
+                xn0 = fmaf(hi.y, hi.y, xn0);
+                xn0 = fmaf(hi.z, hi.z, xn0);
+                xn0 = fmaf(hi.w, hi.w, xn0);
+                asm volatile("" : "+v"(xn0));
+            }
+            const f32x4 m = h ? hi : lo;
+            const auto xy = __builtin_amdgcn_permlane32_swap(__float_as_uint(m.x), __float_as_uint(m.y), false, false);
+            const auto zw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m.z), __float_as_uint(m.w), false, false);
+            const int sb = ch * (CH / 2) + 4 * j;
+            xf[sb + 0] = __uint_as_float(xy[0]);
+            xf[sb + 1] = __uint_as_float(zw[0]);
+            xf[sb + 2] = __uint_as_float(xy[1]);
+            xf[sb + 3] = __uint_as_float(zw[1]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+template <int DP, int WAVES, int METRIC, int MODE>
+__global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_sweep_aux(const AuxParams p) {
+    using G = Geo<DP, WAVES>;
+    constexpr int RS = G::RS, RS4 = G::RS4, SUB = G::SUB, NG = DP / 8;
+    constexpr bool EUCLID = (METRIC == VQ_METRIC_EUCLID);
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4 *tile4 = (f32x4 *)smem;
+    lds_f32x4 *tile4_lds = (lds_f32x4 *)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y;
+    const long long row0 = ((long long)blockIdx.x * WAVES + wave) * 32;
+    const float *xh = p.x + (long long)head * p.x_hs;
+    const float INF = __builtin_inff();
+
+    float xf[DP / 2];
+    float xn0;
+    load_x_fragments<DP, WAVES, EUCLID>(xh, p.x_rs, p.M, p.D, p.vec_x, row0, smem, wave, lane, xf, xn0);
+
+    const long long row = row0 + c;
+    const bool row_ok = row < p.M;
+    const float *pk = p.packed + (long long)head * p.pk_hs;
+    const float b_aug = h ? 1.0f : xn0;
+
+    // kAuxStats state: running max / sum of exp over the codes this lane has seen, and the target's logit
+    float run_m = -INF, run_s = 0.0f, tgt_l = -INF;
+    int tgt = -1;
+    if (MODE == kAuxStats && p.target && row_ok) {
+        const long long tv = p.target[(long long)head * p.tgt_hs + row * p.tgt_rs];
+        tgt = (tv >= 0 && tv < p.K) ? (int)tv : (tv < 0 ? -1 : -2);  // -2: out of range -> logit stays -inf
+    }
+    // sub-tile and register that hold the target for THIS lane (-1: never)
+    const int tgt_u = (tgt >= 0 && ((tgt >> 2) & 1) == h) ? (tgt >> 5) : -1;
+    const int tgt_r = (tgt & 3) + 4 * ((tgt >> 3) & 3);
+
+    auto stage = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < (G::TILE_CHUNKS + WAVES - 1) / WAVES; ++i) {
+            const int ck = i * WAVES + wave;
+            if (ck < G::TILE_CHUNKS)
+                lds_dma16(pk, p.pk_bytes, lane * 16, (tile * G::TILE_F4 + ck * 64) * 16,
+                          tile4_lds + buf * G::BUF_F4 + ck * 64);
+        }
+    };
+
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < p.ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < p.ntiles) stage(t + 1, cur ^ 1);
+#pragma unroll 1
+        for (int st = 0; st < SUB; ++st) {
+            const int u = t * SUB + st;
+            if (u * kTileCodes >= p.K) break;  // wave-uniform: nothing but padding from here on
+            const f32x4 *tb = tile4 + cur * G::BUF_F4 + st * (kTileCodes * RS4);
+            const f32x4 *ta = tb + c * RS4 + h;
+            f32x4 a[NG];
+            f32x16 acc = {0};
+            const float cnv = EUCLID ? ((const float *)tb)[c * RS + DP] : 0.0f;
+            mfma_prefetch<DP>(a, ta);
+            mfma_range<DP, 0, NG>(acc, a, ta, xf);
+            if (EUCLID) {
+                const float a_aug = h ? cnv : 1.0f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, acc, 0, 0, 0);
+            }
+            const int cbase = u * kTileCodes + 4 * h;
+            if (MODE == kAuxSims) {
+                float *srow = p.sims + (long long)head * p.sims_hs + row * p.sims_rs;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float tv = acc[4 * g + e];
+                        v[e] = EUCLID ? -sqrtf(fmaxf(tv, 0.0f)) : tv;  // correctly rounded, like the search
+                    }
+                    const int code = cbase + 8 * g;
+                    if (row_ok) {
+                        if (p.vec_s) {
+                            if (code < p.K) *(f32x4 *)(srow + code) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (code + e < p.K) srow[code + e] = v[e];
+                        }
+                    }
+                }
+            } else {
+                float l[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float tv = acc[r];
+                    l[r] = EUCLID ? -p.scale * __builtin_amdgcn_sqrtf(fmaxf(tv, 0.0f)) : p.scale * tv;
+                }
+                if (u * kTileCodes + kTileCodes > p.K) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (cbase + (r & 3) + 8 * (r >> 2) >= p.K) l[r] = -INF;
+                }
+                if (u == tgt_u) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tgt_l = (r == tgt_r) ? l[r] : tgt_l;
+                }
+                float tm = l[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tm = fmaxf(tm, l[r]);
+                if (tm > run_m) {
+                    run_s *= __expf(run_m - tm);  // exp(-inf) = 0 on the first visit
+                    run_m = tm;
+                }
+                if (run_m > -INF) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) run_s += __expf(l[r] - run_m);
+                }
+            }
+        }
+        __syncthreads();  // next tile landed, everybody is done reading this one
+    }
+
+    if (MODE == kAuxStats) {
+        const float om = __shfl_xor(run_m, 32), os = __shfl_xor(run_s, 32), ot = __shfl_xor(tgt_l, 32);
+        const float mm = fmaxf(run_m, om);  // lane half 0 always saw code 0, so mm is finite
+        const float s = (run_m > -INF ? run_s * __expf(run_m - mm) : 0.0f) + (om > -INF ? os * __expf(om - mm) : 0.0f);
+        if (h == 0 && row_ok) {
+            const long long o = (long long)head * p.M + row;
+            p.lse[o] = mm + __logf(s);
+            if (p.tgt_logit) p.tgt_logit[o] = (tgt == -1) ? 0.0f : fmaxf(tgt_l, ot);
+        }
+    }
+}
+
+// scalar fallback for the similarity matrix (D > 512, cross-check): one thread per (row, code)
+template <int METRIC>
+__global__ void __launch_bounds__(256) vq_sims_simple(const float *__restrict__ x, long long x_rs, long long x_hs,
+                                                      const float *__restrict__ cb, long long cb_hs, long long M, int K,
+                                                      int D, float *__restrict__ sims, long long sims_rs, long long sims_hs) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= M * K) return;
+    const long long row = gid / K;
+    const int k = (int)(gid % K);
+    const int head = blockIdx.y;
+    const float *xr = x + (long long)head * x_hs + row * x_rs;
+    const float *cr = cb + (long long)head * cb_hs + (long long)k * D;
+    float acc = 0.0f;
+    if (METRIC == VQ_METRIC_EUCLID) {
+        float xn = 0.0f, cn = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            xn = fmaf(xr[d], xr[d], xn);
+            cn = fmaf(cr[d], cr[d], cn);
+            acc = fmaf(xr[d], -2.0f * cr[d], acc);
+        }
+        acc = fmaf(1.0f, xn, acc);
+        acc = fmaf(cn, 1.0f, acc);
+        acc = -sqrtf(fmaxf(acc, 0.0f));
+    } else {
+        for (int d = 0; d < D; ++d) acc = fmaf(xr[d], cr[d], acc);
+    }
+    sims[(long long)head * sims_hs + row * sims_rs + k] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // scalar-FMA fallback search: one thread per row, any D / K.  Same chain order as the MFMA kernel
 // (and the oracle), so it doubles as an on-device cross-check.  Emits packed keys.
 // ------------------------------------------------------------------------------------------------
@@ -1031,6 +1287,47 @@ int launch_search(int DP, int waves, const SearchParams &p, int H, int splits, i
         case 512: return launch_search_m<512, 4>(p, H, splits, metric, s);
     }
     return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
+}
+
+
+template <int DP, int WAVES, int METRIC, int MODE>
+int launch_aux_t(const AuxParams &p, int H, hipStream_t s) {
+    using G = Geo<DP, WAVES>;
+    const size_t lds = (size_t)G::MAIN_FLOATS * 4;
+    auto kern = vq_sweep_aux<DP, WAVES, METRIC, MODE>;
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        attr_done = true;
+    }
+    const long long rows_per_wg = 32ll * WAVES;
+    dim3 grid((unsigned)((p.M + rows_per_wg - 1) / rows_per_wg), (unsigned)H, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_sweep_aux launch");
+    return 0;
+}
+
+template <int DP, int WAVES>
+int launch_aux_m(const AuxParams &p, int H, int metric, int mode, hipStream_t s) {
+    if (mode == kAuxSims) {
+        if (metric == VQ_METRIC_EUCLID) return launch_aux_t<DP, WAVES, VQ_METRIC_EUCLID, kAuxSims>(p, H, s);
+        return launch_aux_t<DP, WAVES, VQ_METRIC_DOT, kAuxSims>(p, H, s);
+    }
+    if (metric == VQ_METRIC_EUCLID) return launch_aux_t<DP, WAVES, VQ_METRIC_EUCLID, kAuxStats>(p, H, s);
+    return launch_aux_t<DP, WAVES, VQ_METRIC_DOT, kAuxStats>(p, H, s);
+}
+
+int launch_aux(int DP, const AuxParams &p, int H, int metric, int mode, hipStream_t s) {
+    switch (DP) {
+        case 32: return launch_aux_m<32, 4>(p, H, metric, mode, s);
+        case 64: return launch_aux_m<64, 4>(p, H, metric, mode, s);
+        case 128: return launch_aux_m<128, 4>(p, H, metric, mode, s);
+        case 256: return launch_aux_m<256, 4>(p, H, metric, mode, s);
+        case 512: return launch_aux_m<512, 4>(p, H, metric, mode, s);
+    }
+    return fail(VQ_E_UNSUPPORTED, "vq_sweep_aux: unsupported padded dim");
 }
 
 bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -1333,6 +1630,70 @@ int vq_ema_update_f32(float *cluster_size, float *embed_avg, float *embeddings, 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "vq_ema_update launch");
     return 0;
+}
+
+static int fill_aux_params(AuxParams &p, const vq_args *a, const char *who) {
+    memset(&p, 0, sizeof(p));
+    if (!a->packed) return fail(VQ_E_BADARG, "vq: packed codebook is null");
+    if (vq_packed_floats(a->K, a->D) * 4 >= (1ll << 31))
+        return fail(VQ_E_UNSUPPORTED, "vq: packed codebook image >= 2 GiB (shard the codebook)");
+    (void)who;
+    p.x = a->x; p.x_rs = a->x_rs; p.x_hs = a->x_hs;
+    p.packed = a->packed; p.pk_hs = a->pk_hs;
+    p.pk_bytes = (unsigned)(vq_packed_floats(a->K, a->D) * 4);
+    p.M = a->M; p.K = a->K; p.D = a->D;
+    const int tc = kTileCodes * sub_tiles(padded_dim(a->D));
+    p.ntiles = (a->K + tc - 1) / tc;
+    p.vec_x = (a->D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x)) ? 1 : 0;
+    return 0;
+}
+
+int vq_similarities_f32(const vq_args *a, float *sims, int64_t sims_rs, int64_t sims_hs, void *stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (a->M == 0) return 0;
+    if (!sims) return fail(VQ_E_BADARG, "vq_similarities: sims is null");
+    hipStream_t s = (hipStream_t)stream;
+    const int DP = padded_dim(a->D);
+    if ((a->flags & VQ_F_FORCE_SIMPLE) || DP == 0) {
+        if (!a->cb) return fail(VQ_E_BADARG, "vq_similarities: natural codebook required for the scalar kernel");
+        const long long n = a->M * (long long)a->K;
+        if ((n + 255) / 256 > 0x7FFFFFFFll) return fail(VQ_E_UNSUPPORTED, "vq_similarities: chunk too large for the scalar kernel");
+        dim3 grid((unsigned)((n + 255) / 256), (unsigned)a->H);
+        if (a->metric == VQ_METRIC_EUCLID)
+            hipLaunchKernelGGL(vq_sims_simple<VQ_METRIC_EUCLID>, grid, dim3(256), 0, s, a->x, a->x_rs, a->x_hs, a->cb,
+                               a->cb_hs, a->M, a->K, a->D, sims, (long long)sims_rs, (long long)sims_hs);
+        else
+            hipLaunchKernelGGL(vq_sims_simple<VQ_METRIC_DOT>, grid, dim3(256), 0, s, a->x, a->x_rs, a->x_hs, a->cb,
+                               a->cb_hs, a->M, a->K, a->D, sims, (long long)sims_rs, (long long)sims_hs);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "vq_sims_simple launch");
+        return 0;
+    }
+    AuxParams p;
+    rc = fill_aux_params(p, a, "vq_similarities");
+    if (rc) return rc;
+    p.sims = sims; p.sims_rs = sims_rs; p.sims_hs = sims_hs;
+    p.vec_s = (a->K % 4 == 0 && sims_rs % 4 == 0 && sims_hs % 4 == 0 && aligned16(sims)) ? 1 : 0;
+    return launch_aux(DP, p, a->H, a->metric, kAuxSims, s);
+}
+
+int vq_softmax_stats_f32(const vq_args *a, float scale, const int64_t *target, int64_t tgt_rs, int64_t tgt_hs, float *lse,
+                         float *target_logit, void *stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (a->M == 0) return 0;
+    if (!lse) return fail(VQ_E_BADARG, "vq_softmax_stats: lse is null");
+    if (target && !target_logit) return fail(VQ_E_BADARG, "vq_softmax_stats: target_logit is null");
+    const int DP = padded_dim(a->D);
+    if (DP == 0) return fail(VQ_E_UNSUPPORTED, "vq_softmax_stats: D > 512 is not supported (use vq_similarities_f32 chunks)");
+    AuxParams p;
+    rc = fill_aux_params(p, a, "vq_softmax_stats");
+    if (rc) return rc;
+    p.scale = scale;
+    p.target = (const long long *)target; p.tgt_rs = tgt_rs; p.tgt_hs = tgt_hs;
+    p.lse = lse; p.tgt_logit = target_logit;
+    return launch_aux(DP, p, a->H, a->metric, kAuxStats, (hipStream_t)stream);
 }
 
 int vq_nearest_f32(const vq_args *a, void *stream) {

@@ -112,6 +112,10 @@ def load():
         lib.vq_ema_update_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_float, ctypes.c_float, ctypes.c_int, _vp]
         lib.vq_ema_update_f32.restype = ctypes.c_int
+        lib.vq_similarities_f32.argtypes = [ap, _vp, _i64, _i64, _vp]
+        lib.vq_similarities_f32.restype = ctypes.c_int
+        lib.vq_softmax_stats_f32.argtypes = [ap, ctypes.c_float, _vp, _i64, _i64, _vp, _vp, _vp]
+        lib.vq_softmax_stats_f32.restype = ctypes.c_int
         lib.vq_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         lib.vq_device_info.restype = ctypes.c_int
         _lib = lib
@@ -121,7 +125,7 @@ def load():
 EXPORTED_SYMBOLS = (
     "vq_packed_floats", "vq_pack_codebooks_f32", "vq_workspace_bytes", "vq_quantize_f32", "vq_nearest_f32",
     "vq_residual_f32", "vq_keys_init", "vq_search_keys_f32", "vq_finalize_keys_f32", "vq_last_error",
-    "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32",
+    "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32", "vq_similarities_f32", "vq_softmax_stats_f32",
 )
 
 
@@ -339,3 +343,58 @@ def ema_update(cluster_size: torch.Tensor, embed_avg: torch.Tensor, embeddings: 
         _check(load().vq_ema_update_f32(cluster_size.data_ptr(), embed_avg.data_ptr(), embeddings.data_ptr(),
                                         counts.data_ptr(), sums.data_ptr(), total.data_ptr(), H, K, D, float(decay),
                                         float(eps), 1 if l2norm else 0, _stream_ptr(dev)), "vq_ema_update_f32")
+
+
+def _aux_args(x: torch.Tensor, cb: torch.Tensor, metric: int, packed, flags: int):
+    _require_gpu(x, cb)
+    assert x.dtype == torch.float32 and cb.dtype == torch.float32
+    assert x.dim() == 3 and cb.dim() == 3 and cb.is_contiguous()
+    H, M, D = x.shape
+    Hc, K, Dc = cb.shape
+    assert Hc == H and Dc == D
+    if packed is None:
+        packed = pack_codebooks(cb, metric)
+    x_rs, x_hs = _row_strides(x)
+    a = VqArgs()
+    a.H, a.Q, a.M, a.K, a.D, a.metric, a.flags = H, 1, M, K, D, metric, flags
+    a.x, a.x_rs, a.x_hs = x.data_ptr(), x_rs, x_hs
+    a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), K * D, 0
+    a.packed, a.pk_hs, a.pk_qs = packed.data_ptr(), packed.shape[-1], 0
+    return a, packed
+
+
+def similarities(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, packed: torch.Tensor | None = None,
+                 flags: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
+    """x [H, M, D] (strided rows ok), cb [H, K, D] -> sims [H, M, K]: -cdist (Euclid) or dot products, the values the
+    search compares (codebooks.py:386).  The caller bounds M (row chunks): this DOES materialise [H, M, K]."""
+    a, packed = _aux_args(x, cb, metric, packed, flags)
+    H, M, K = a.H, a.M, a.K
+    if out is None:
+        out = torch.empty((H, M, K), dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (H, M, K) and (K == 1 or out.stride(2) == 1)
+    with torch.cuda.device(x.device):
+        _check(load().vq_similarities_f32(ctypes.byref(a), out.data_ptr(), int(out.stride(1)), int(out.stride(0)),
+                                          _stream_ptr(x.device)), "vq_similarities_f32")
+    return out
+
+
+def softmax_stats(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, scale: float = 1.0,
+                  target: torch.Tensor | None = None, packed: torch.Tensor | None = None):
+    """Per row log-sum-exp of ``scale * similarity`` over the codebook and the logit of ``target`` [H, M] int64
+    (negative = ignored -> 0).  -> (lse [H, M], target_logit [H, M] | None).  [M, K] is never materialised."""
+    a, packed = _aux_args(x, cb, metric, packed, 0)
+    H, M = a.H, a.M
+    dev = x.device
+    lse = torch.empty((H, M), dtype=torch.float32, device=dev)
+    tl = None
+    t_ptr, t_rs, t_hs = None, 0, 0
+    if target is not None:
+        _require_gpu(target)
+        assert target.dtype == torch.int64 and tuple(target.shape) == (H, M)
+        tl = torch.empty((H, M), dtype=torch.float32, device=dev)
+        t_ptr, t_rs, t_hs = target.data_ptr(), int(target.stride(1)), int(target.stride(0))
+    with torch.cuda.device(dev):
+        _check(load().vq_softmax_stats_f32(ctypes.byref(a), float(scale), t_ptr, t_rs, t_hs, lse.data_ptr(),
+                                           tl.data_ptr() if tl is not None else None, _stream_ptr(dev)),
+               "vq_softmax_stats_f32")
+    return lse, tl
