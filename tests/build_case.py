@@ -13,6 +13,15 @@ def make_mask(b, n):
     return mask
 
 
+def given_indices(case, shape, K):
+    """Same seeded teacher-forcing targets as tests/golden/make_golden.py:given_indices."""
+    g = torch.Generator().manual_seed(99)
+    t = torch.randint(0, K, shape, generator=g)
+    if case.get("ignore_some", False):
+        t.view(-1)[::5] = -1
+    return t
+
+
 def build(case, arrays=None, device="cpu"):
     """-> (module, x, forward_kwargs, codebook_tensor)."""
     import vector_quantization as vq
@@ -21,7 +30,7 @@ def build(case, arrays=None, device="cpu"):
     kind = case["kind"]
     x = make_x(case["x_shape"], case["cls"])
     kwargs = {}
-    if kind == "vq":
+    if kind in ("vq", "vqloss"):
         dim, K = case["dim"], case["K"]
         heads = case.get("heads", 1)
         separate = case.get("separate_codebook_per_head", False)
@@ -33,7 +42,8 @@ def build(case, arrays=None, device="cpu"):
                                 weights_regularization=case.get("weights_regularization", "identity"),
                                 **case.get("cb_extra", {}))
         mod = vq.VectorQuantize(dim=dim, codebook_params=params, codebook_dim=codebook_dim, heads=heads,
-                                separate_codebook_per_head=separate, channel_last=case.get("channel_last", True))
+                                separate_codebook_per_head=separate, channel_last=case.get("channel_last", True),
+                                **case.get("vq_extra", {}))
         cb = make_codebook(h, K, d, case["cls"])
         if case.get("weights_regularization", "identity") == "l2norm":
             cb = l2norm(cb)
@@ -48,6 +58,10 @@ def build(case, arrays=None, device="cpu"):
                 mod.project_out.bias.copy_(torch.from_numpy(arrays["proj_out_b"]))
         if case.get("mask", False):
             kwargs["mask"] = make_mask(x.shape[0], x.shape[1]).to(device)
+        if case.get("given_indices", False):
+            b = x.shape[0]
+            n = x.numel() // (b * dim)
+            kwargs["indices"] = given_indices(case, (b, n, heads) if heads > 1 else (b, n), K).to(device)
     elif kind == "rvq":
         dim, K, Q = case["dim"], case["K"], case["Q"]
         shared = case.get("shared_codebook", False)

@@ -71,3 +71,41 @@ def compare(case, arrays, meta, outputs, x, cb, mod=None):
     if "all_codes" in arrays and len(outputs) > 3:
         np.testing.assert_allclose(outputs[3].detach().cpu().numpy(), arrays["all_codes"], atol=Q_TOL, rtol=0)
     return n_mismatch
+
+
+# loss values: 1e-5 (north_star tolerance).  Gradients: 1e-5 relative to the largest gradient entry.  The diversity loss
+# multiplies fp32 distances by its temperature before the softmax, so rounding differences between the reference's
+# MKL sgemm and the k-ordered chain are amplified by that factor: tolerance scales with max(1, temperature).
+def compare_loss(case, arrays, meta, mod, x, kwargs):
+    """Run ``mod`` on ``x`` (requires_grad), backprop the loss, compare with the golden of a similarity-consuming case."""
+    x = x.detach().clone().requires_grad_(True)
+    temp = case.get("vq_extra", {}).get("codebook_diversity_temperature", 100.0) \
+        if case.get("vq_extra", {}).get("codebook_diversity_loss_weight", 0.0) > 0 else 1.0
+    amp = max(1.0, temp)
+    if case.get("given_indices", False):
+        q, loss = mod(x, **kwargs)
+        assert loss.ndim == 0
+    else:
+        q, idx, loss, breakdown = mod(x, return_loss_breakdown=True, **kwargs)
+        np.testing.assert_array_equal(idx.detach().cpu().numpy(), arrays["idx"].astype(np.int64))
+        got_b = np.asarray([float(v.detach()) for v in breakdown], dtype=np.float32)
+        np.testing.assert_allclose(got_b, arrays["breakdown"], rtol=1e-5 * amp, atol=1e-5 * amp)
+    loss.sum().backward()
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), arrays["loss"], rtol=1e-5 * amp, atol=1e-5 * amp)
+    assert list(q.shape) == meta["q_shape"], (q.shape, meta["q_shape"])
+    flat_q = q.detach().cpu().reshape(-1, q.shape[-1]).numpy()
+    np.testing.assert_allclose(flat_q[arrays["q_rows"]], arrays["q_vals"], atol=Q_TOL, rtol=0)
+    grad = x.grad.detach().cpu()
+    gcl = grad if case.get("channel_last", True) else grad.movedim(1, -1)
+    gflat = gcl.reshape(-1, gcl.shape[-1]).numpy()
+    scale = float(np.abs(arrays["g_vals"]).max()) if "g_full" not in arrays else float(np.abs(arrays["g_full"]).max())
+    tol = 1e-5 * amp * max(scale, 1e-12)
+    np.testing.assert_allclose(gflat[arrays["g_rows"]], arrays["g_vals"], atol=tol, rtol=1e-4 * amp)
+    if "g_full" in arrays:
+        np.testing.assert_allclose(grad.numpy(), arrays["g_full"], atol=tol, rtol=1e-4 * amp)
+    if "ema_embeddings" in arrays:
+        np.testing.assert_allclose(mod._codebook.embeddings.detach().cpu().numpy(), arrays["ema_embeddings"], rtol=1e-4,
+                                   atol=1e-5)
+    s = float(grad.double().abs().sum())
+    assert abs(s - meta["g_checksum"][1]) <= 1e-4 * amp * max(1e-12, meta["g_checksum"][1]), (s, meta["g_checksum"])
+    return float(loss.detach().sum())

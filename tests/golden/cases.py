@@ -85,3 +85,53 @@ CASES = [
 ]
 
 CASES_BY_NAME = {c["name"]: c for c in CASES}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Consumers of the similarity matrix: cross-entropy commitment loss, cross entropy against given
+# indices, codebook diversity loss.  Goldens hold the loss, the returned tensors and d loss / d x from the imported
+# reference (make_golden.py: run_vqloss).  All in train mode with a frozen codebook unless stated.
+# ---------------------------------------------------------------------------------------------------------------
+def _vql(name, dim, K, x_shape, **kw):
+    d = dict(name=name, kind="vqloss", dim=dim, K=K, x_shape=list(x_shape), cls="S", training=True)
+    d.update(kw)
+    return d
+
+
+_CE = dict(commitment_use_cross_entropy_loss=True)
+
+LOSS_CASES = [
+    _vql("ce_commit", 64, 256, (4, 64, 64), vq_extra=_CE),
+    _vql("ce_commit_mask", 64, 256, (3, 40, 64), vq_extra=_CE, mask=True),
+    _vql("ce_commit_mh_sep", 64, 128, (2, 50, 64), vq_extra=_CE, heads=2, codebook_dim=32, separate_codebook_per_head=True),
+    _vql("ce_commit_mh_shared", 64, 128, (2, 50, 64), vq_extra=_CE, heads=2, codebook_dim=32),
+    _vql("ce_commit_mh_mask", 64, 128, (3, 20, 64), vq_extra=_CE, heads=2, codebook_dim=32, separate_codebook_per_head=True,
+         mask=True),
+    _vql("ce_commit_cos", 64, 256, (4, 64, 64), vq_extra=_CE, use_cosine_sim=True, transform_input="l2norm",
+         weights_regularization="l2norm"),
+    _vql("ce_commit_cfg2", 256, 1024, (2, 512, 256), vq_extra=_CE),
+    _vql("ce_commit_odd", 100, 301, (3, 37, 100), vq_extra=_CE),
+    _vql("ce_commit_w", 64, 256, (4, 64, 64), vq_extra=dict(commitment_use_cross_entropy_loss=True, commitment_weight=0.25)),
+    _vql("ce_indices", 64, 256, (4, 64, 64), given_indices=True),
+    _vql("ce_indices_eval", 64, 256, (4, 64, 64), given_indices=True, training=False),
+    _vql("ce_indices_ignore", 64, 256, (4, 64, 64), given_indices=True, ignore_some=True),
+    _vql("ce_indices_mh_sep", 64, 128, (2, 50, 64), given_indices=True, heads=2, codebook_dim=32,
+         separate_codebook_per_head=True),
+    _vql("ce_indices_mh_shared", 64, 128, (2, 50, 64), given_indices=True, heads=2, codebook_dim=32),
+    _vql("ce_indices_img", 32, 64, (2, 32, 6, 6), given_indices=True, channel_last=False),
+    _vql("div", 64, 256, (4, 64, 64), vq_extra=dict(codebook_diversity_loss_weight=0.5)),
+    _vql("div_t1", 64, 256, (4, 64, 64), vq_extra=dict(codebook_diversity_loss_weight=0.5, codebook_diversity_temperature=1.0)),
+    _vql("div_mh_shared", 64, 128, (2, 50, 64), heads=2, codebook_dim=32,
+         vq_extra=dict(codebook_diversity_loss_weight=1.0, codebook_diversity_temperature=2.0)),
+    _vql("div_mh_sep", 64, 128, (2, 50, 64), heads=2, codebook_dim=32, separate_codebook_per_head=True,
+         vq_extra=dict(codebook_diversity_loss_weight=1.0, codebook_diversity_temperature=2.0)),
+    _vql("div_cos", 64, 256, (4, 64, 64), use_cosine_sim=True, transform_input="l2norm", weights_regularization="l2norm",
+         vq_extra=dict(codebook_diversity_loss_weight=0.5, codebook_diversity_temperature=10.0)),
+    _vql("div_ce", 64, 256, (4, 64, 64), vq_extra=dict(codebook_diversity_loss_weight=0.5, codebook_diversity_temperature=1.0,
+                                                       commitment_use_cross_entropy_loss=True)),
+    # EMA update running (codebook not frozen): losses are evaluated against the pre-update codebook
+    _vql("ce_commit_ema", 64, 256, (4, 64, 64), vq_extra=_CE, freeze_codebook=False,
+         cb_extra=dict(threshold_ema_dead_code=0)),
+]
+
+LOSS_CASES_BY_NAME = {c["name"]: c for c in LOSS_CASES}

@@ -24,7 +24,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-from cases import CASES  # noqa: E402
+from cases import CASES, LOSS_CASES  # noqa: E402
 from gen import CB_SEED, checksum, l2norm, make_codebook, make_rvq_codebooks, make_x  # noqa: E402
 
 
@@ -125,6 +125,93 @@ def run_vq(ref, ref_cb, c):
     return arrays, meta
 
 
+def given_indices(c, rows_shape, K):
+    """Teacher-forcing targets for the ``indices=`` cases (seeded; shared with tests/build_case.py)."""
+    g = torch.Generator().manual_seed(99)
+    t = torch.randint(0, K, rows_shape, generator=g)
+    if c.get("ignore_some", False):
+        t.view(-1)[::5] = -1
+    return t
+
+
+def run_vqloss(ref, ref_cb, c):
+    """Similarity-consuming losses: loss value(s), returned tensors and d loss / d x of the reference."""
+    dim, K = c["dim"], c["K"]
+    heads = c.get("heads", 1)
+    separate = c.get("separate_codebook_per_head", False)
+    codebook_dim = c.get("codebook_dim", None)
+    d = codebook_dim if codebook_dim is not None else dim
+    h = heads if separate else 1
+    channel_last = c.get("channel_last", True)
+    params = ref_cb.CodebookParams(
+        dim=d, codebook_size=K, use_cosine_sim=c.get("use_cosine_sim", False),
+        transform_input=c.get("transform_input", "identity"),
+        weights_regularization=c.get("weights_regularization", "identity"), **c.get("cb_extra", {}))
+    torch.manual_seed(777)
+    mod = ref.VectorQuantize(dim=dim, codebook_params=params, codebook_dim=codebook_dim, heads=heads,
+                             separate_codebook_per_head=separate, channel_last=channel_last, **c.get("vq_extra", {}))
+    assert not mod.has_projections
+    cb = make_codebook(h, K, d, c["cls"])
+    if c.get("weights_regularization", "identity") == "l2norm":
+        cb = l2norm(cb)
+    with torch.no_grad():
+        mod._codebook.embeddings.copy_(cb)
+        mod._codebook.embed_avg.copy_(cb)
+    x = make_x(c["x_shape"], c["cls"]).requires_grad_(True)
+    kwargs = {}
+    if c.get("mask", False):
+        kwargs["mask"] = make_mask(x.shape[0], x.shape[1])
+    if c["training"]:
+        mod.train()
+        kwargs["freeze_codebook"] = c.get("freeze_codebook", True)
+    else:
+        mod.eval()
+    arrays = {}
+    if c.get("given_indices", False):
+        b = x.shape[0]
+        n = x.numel() // (b * dim)
+        shape = (b, n, heads) if heads > 1 else (b, n)
+        kwargs["indices"] = given_indices(c, shape, K)
+        q, loss = mod(x, **kwargs)
+        idx = None
+    else:
+        q, idx, loss, breakdown = mod(x, return_loss_breakdown=True, **kwargs)
+        arrays["idx"] = idx.numpy().astype(np.int32)
+        arrays["breakdown"] = np.asarray([float(v) for v in breakdown], dtype=np.float32)
+    loss.sum().backward()
+    grad = x.grad.detach()
+    arrays["loss"] = loss.detach().numpy().astype(np.float32)
+    arrays["q_shape"] = np.asarray(q.shape, dtype=np.int64)
+    flat_q = q.detach().reshape(-1, q.shape[-1])
+    rows, vals = sample_rows(flat_q, flat_q.shape[-1])
+    arrays["q_rows"], arrays["q_vals"] = rows, vals
+    gcl = grad if channel_last else grad.movedim(1, -1)
+    rows, vals = sample_rows(gcl, gcl.shape[-1])
+    arrays["g_rows"], arrays["g_vals"] = rows, vals
+    if grad.numel() <= 1 << 16:
+        arrays["g_full"] = grad.numpy().copy()
+    if c["training"] and not c.get("freeze_codebook", True):
+        arrays["ema_embeddings"] = mod._codebook.embeddings.detach().numpy().copy()
+    meta = dict(x_checksum=checksum(x.detach()), cb_checksum=checksum(cb), q_checksum=checksum(q.detach()),
+                g_checksum=checksum(grad), q_shape=list(q.shape))
+    return arrays, meta
+
+
+def run_orthogonal(ref):
+    """utils/losses.py:23-28 on seeded codebooks (the module path crashes in the fork: ``_codebook.embed``)."""
+    from vector_quantization.utils.losses import orthogonal_loss_fn
+
+    arrays = {}
+    for i, (h, k, d) in enumerate([(1, 256, 64), (4, 100, 32), (1, 1024, 256)]):
+        cb = make_codebook(h, k, d, "S", seed=CB_SEED + i).requires_grad_(True)
+        v = orthogonal_loss_fn(cb)
+        v.backward()
+        arrays[f"shape{i}"] = np.asarray([h, k, d], dtype=np.int64)
+        arrays[f"value{i}"] = np.asarray(float(v), dtype=np.float64)
+        arrays[f"grad_rows{i}"] = cb.grad[:, :4].numpy().copy()
+    return arrays, dict(n=3)
+
+
 def run_rvq(ref, ref_cb, c):
     dim, K, Q = c["dim"], c["K"], c["Q"]
     params = ref_cb.CodebookParams(dim=dim, codebook_size=K, **c.get("cb_extra", {}))
@@ -193,10 +280,16 @@ def main():
     out_dir = os.path.join(HERE, "data")
     os.makedirs(out_dir, exist_ok=True)
     only = set(sys.argv[1:])
-    for c in CASES:
+    if not only or "orthogonal_fn" in only:
+        arrays, meta = run_orthogonal(ref)
+        meta.update(torch_version=torch.__version__, generator="tests/golden/make_golden.py importing /root/reference @ 2024_10_08")
+        arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(out_dir, "orthogonal_fn.npz"), **arrays)
+        print("orthogonal_fn", [float(arrays[f"value{i}"]) for i in range(3)])
+    for c in CASES + LOSS_CASES:
         if only and c["name"] not in only:
             continue
-        fn = dict(vq=run_vq, rvq=run_rvq, grvq=run_grvq)[c["kind"]]
+        fn = dict(vq=run_vq, rvq=run_rvq, grvq=run_grvq, vqloss=run_vqloss)[c["kind"]]
         arrays, meta = fn(ref, ref_cb, c)
         meta.update(case=c, torch_version=torch.__version__, num_threads=torch.get_num_threads(),
                     blas="mkl" if torch.backends.mkl.is_available() else "other",
@@ -204,7 +297,7 @@ def main():
         arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         path = os.path.join(out_dir, c["name"] + ".npz")
         np.savez_compressed(path, **arrays)
-        print(f"{c['name']:>20s}  idx{tuple(arrays['idx'].shape)}  loss={arrays['loss'].ravel()[:3]}  "
+        print(f"{c['name']:>20s}  idx{tuple(arrays['idx'].shape) if 'idx' in arrays else ()}  loss={arrays['loss'].ravel()[:3]}  "
               f"{os.path.getsize(path) / 1024:.1f} KiB")
 
 

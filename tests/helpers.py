@@ -53,6 +53,26 @@ class OracleBackend:
             (torch.from_numpy(err) if want_sq_err else None)
 
 
+    @staticmethod
+    def similarities(x, cb, *, metric, out=None):
+        xn = np.ascontiguousarray(x.detach().cpu().numpy(), dtype=np.float32)
+        cbn = np.ascontiguousarray(cb.detach().cpu().numpy(), dtype=np.float32)
+        sims = torch.from_numpy(np.stack([vq_oracle.similarities(xn[h], cbn[h], metric) for h in range(xn.shape[0])]))
+        if out is not None:
+            out.copy_(sims)
+            return out
+        return sims
+
+    @staticmethod
+    def softmax_stats(x, cb, *, metric, scale, target=None):
+        logits = OracleBackend.similarities(x, cb, metric=metric).double() * scale
+        lse = torch.logsumexp(logits, -1).float()
+        if target is None:
+            return lse, None
+        tl = torch.gather(logits, -1, target.clamp(min=0)[..., None])[..., 0]
+        return lse, torch.where(target >= 0, tl, torch.zeros_like(tl)).float()
+
+
 class OracleShardOps:
     """CPU stand-in for sharded._NativeShardOps (gloo tests)."""
 

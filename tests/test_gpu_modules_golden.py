@@ -9,8 +9,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from build_case import build  # noqa: E402
-from cases import CASES  # noqa: E402
-from check_case import compare  # noqa: E402
+from cases import CASES, LOSS_CASES  # noqa: E402
+from check_case import compare, compare_loss  # noqa: E402
 from helpers import load_golden  # noqa: E402
 
 
@@ -32,6 +32,56 @@ def test_module_matches_reference_golden_on_gpu(case):
         outputs = mod(x, **kwargs)
     torch.cuda.synchronize()
     compare(case, arrays, meta, outputs, x, cb, mod)
+
+
+@pytest.mark.parametrize("case", LOSS_CASES, ids=[c["name"] for c in LOSS_CASES])
+def test_similarity_consuming_losses_match_reference_golden_on_gpu(case):
+    """SURVEY 8f rank 3 on the native kernels (vq_softmax_stats_f32 forward, vq_similarities_f32 chunks backward)."""
+    arrays, meta = load_golden(case["name"])
+    mod, x, kwargs, _ = build(case, arrays, device="cuda:0")
+    compare_loss(case, arrays, meta, mod, x, kwargs)
+
+
+@pytest.mark.parametrize("name", ["ce_commit", "ce_commit_cfg2", "ce_indices_ignore", "div_t1", "div_mh_shared"])
+def test_losses_are_chunk_size_independent_on_gpu(name, monkeypatch):
+    from cases import LOSS_CASES_BY_NAME
+    from vector_quantization import losses
+
+    monkeypatch.setattr(losses, "CHUNK_BYTES", 1)  # 128-row chunks
+    case = LOSS_CASES_BY_NAME[name]
+    arrays, meta = load_golden(name)
+    mod, x, kwargs, _ = build(case, arrays, device="cuda:0")
+    compare_loss(case, arrays, meta, mod, x, kwargs)
+
+
+def test_cross_entropy_commitment_full_size_memory_bound():
+    """cfg2 rows (M = 262144, K = 1024): forward + backward of the cross-entropy commitment loss without ever holding
+    the 1 GiB similarity matrix: peak extra memory stays near the chunk bound, gradient equals a chunked torch reference."""
+    import vector_quantization as vq
+    from vector_quantization import losses
+    from vector_quantization.codebooks import CodebookParams
+
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    mod = vq.VectorQuantize(dim=256, codebook_params=CodebookParams(dim=256, codebook_size=1024),
+                            commitment_use_cross_entropy_loss=True).to(dev).train()
+    x = torch.randn(256, 1024, 256, device=dev, requires_grad=True)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    q, idx, loss = mod(x, freeze_codebook=True)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    # outputs (q 256 MiB, idx) + x.grad (256 MiB) + a few chunk-sized temporaries; the full matrix alone would be 1 GiB
+    # for sims plus as much again for the softmax and its gradient
+    assert peak < (256 + 256 + 64) * 2**20 + 6 * losses.CHUNK_BYTES, peak / 2**20
+    codes = mod._codebook.embeddings.detach()
+    for b0 in (0, 131, 255):
+        xs = x.detach()[b0].clone().requires_grad_(True)
+        ce = torch.nn.functional.cross_entropy(-torch.cdist(xs[None], codes)[0], idx[b0], reduction="sum") / (256 * 1024)
+        ce.backward()
+        torch.testing.assert_close(x.grad[b0], xs.grad, rtol=1e-3, atol=1e-9)
 
 
 def test_gpu_equals_oracle_backend_on_all_cases(oracle):

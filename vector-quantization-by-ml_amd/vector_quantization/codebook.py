@@ -151,13 +151,12 @@ class Codebook(nn.Module):
         return out, idx[..., 0], sq_err
 
     def similarities(self, flat: torch.Tensor) -> torch.Tensor:
-        """The [h, M, K] matrix the reference returns on every call (codebooks.py:386,435).  Only its rare
-        consumers need it (cross-entropy / diversity losses), so it is computed on demand with plain
-        PyTorch ops on the tensor's device instead of being produced by the search kernel."""
-        codes = self.current_codes()
-        if self.use_cosine_sim:
-            return torch.einsum("hnd,hcd->hnc", flat.float(), codes)
-        return -torch.cdist(flat.float(), codes)
+        """The [h, M, K] matrix the reference returns on every call (codebooks.py:386,435), on demand
+        (vq_similarities_f32: the very values the search compares).  The losses that consume it never ask for the
+        whole matrix -- see losses.py."""
+        from . import losses
+
+        return losses.similarity_matrix(flat, self.current_codes(), self.metric)
 
     def forward(self, x, mask=None, freeze_codebook=False, return_similarities=False):
         """(quantize, embed_ind, similarities) like the reference; ``similarities`` is None unless asked for."""

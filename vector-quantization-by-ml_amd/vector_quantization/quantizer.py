@@ -18,6 +18,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
+from . import losses
 from .codebook import Codebook
 from .params import CodebookParams
 
@@ -91,11 +92,6 @@ class VectorQuantize(nn.Module):
             raise NotImplementedError("synchronous update rule (sync_update_v) is outside the hot-path build")
         if in_place_codebook_optimizer is not None:
             raise NotImplementedError("in_place_codebook_optimizer is outside the hot-path build")
-        if self.has_codebook_orthogonal_loss or self.has_codebook_diversity_loss or commitment_use_cross_entropy_loss:
-            raise NotImplementedError(
-                "orthogonal / diversity / cross-entropy losses consume the full similarity matrix and are outside "
-                "the MI355X hot-path build (SURVEY 8f rank 3); only the MSE commitment loss is native"
-            )
         self.in_place_codebook_optimizer = None
 
         if sync_codebook is None:
@@ -145,8 +141,7 @@ class VectorQuantize(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, indices=None, mask=None, freeze_codebook=False, return_loss_breakdown=False):
-        if indices is not None:
-            raise NotImplementedError("cross-entropy to given indices needs the similarity matrix (SURVEY 8f rank 3)")
+        return_loss = indices is not None
         orig_input = x
         single_vectors = x.ndim == 2
         if single_vectors:
@@ -182,46 +177,108 @@ class VectorQuantize(nn.Module):
             flat = x4.view(1, rows * heads, head_dim)  # one codebook: heads are just more rows
             out_view, idx_view = q_buf.view(1, rows * heads, head_dim), i_buf.view(1, rows * heads, 1)
 
+        def per_head_rows(t):
+            """[rows, heads] (b, n, head order) -> the [H, M] arrangement of ``flat``'s rows."""
+            return t.permute(1, 0) if self.separate_codebook_per_head else t.reshape(1, rows * heads)
+
         training = self.training
-        want_loss = training and self.has_commitment_loss
+        use_ce = self.commitment_use_cross_entropy_loss
+        want_loss = training and self.has_commitment_loss and not return_loss
+        want_sq_err = want_loss and not use_ce
         flat_mask = None
         if mask is not None:
             per_row = mask.reshape(rows)
-            flat_mask = (per_row[None, :].expand(heads, rows) if self.separate_codebook_per_head
-                         else per_row[:, None].expand(rows, heads).reshape(1, rows * heads))
+            flat_mask = per_head_rows(per_row[:, None].expand(rows, heads))
 
         if not cb.is_initialized:
             cb.seed_with_kmeans(flat.detach(), flat_mask)
             cb.is_initialized = True
 
         loss = torch.zeros(1, device=x.device, dtype=torch.float32)
-        commit_loss = self.zero
+        commit_loss = diversity_loss = orthogonal_loss = self.zero
         cb_grad_from_err = self.learnable_codebook and not freeze_codebook
         if mask is None:
             # the one native launch: search + gather + straight-through + squared error
-            out, idx, sq_err = cb.quantize_flat(flat, ste=training, want_sq_err=want_loss,
+            out, idx, sq_err = cb.quantize_flat(flat, ste=training, want_sq_err=want_sq_err,
                                                 codebook_grad_from_err=cb_grad_from_err, out=out_view, idx=idx_view)
-            if want_loss:
+            if want_sq_err:
                 commit_loss = (sq_err[0] / flat.numel()).to(torch.float32)
         else:
             out, idx, _ = cb.quantize_flat(flat.detach() if not cb_grad_from_err else flat, ste=False, idx=idx_view)
-            if want_loss:
+            if want_sq_err:
                 target = out if cb_grad_from_err else out.detach()
                 commit_loss = ((target - flat) ** 2)[flat_mask].mean()
             if training:
                 out = flat + (out - flat).detach()
+
+        # ---- consumers of the similarity matrix (rare; SURVEY 8f rank 3): evaluated against the codebook the search
+        #      used, i.e. BEFORE the EMA step below rewrites it
+        will_update = training and cb.ema_update and not freeze_codebook
+        needs_sims = return_loss or (training and ((want_loss and use_ce) or self.has_codebook_diversity_loss))
+        if needs_sims:
+            codes, live = cb.current_codes(), None
+            if will_update:
+                # the backward pass recomputes similarities from the pre-update codebook; the reference's autograd then
+                # multiplies with the codebook as it is at backward time (losses.similarity_matrix: live_codes)
+                codes, live = codes.detach().clone().requires_grad_(codes.requires_grad), cb.embeddings
+            if return_loss:
+                # cross entropy of the similarities against GIVEN codes (vector_quantize_pytorch.py:298-299)
+                given = per_head_rows(indices.reshape(rows, heads).to(torch.int64))
+                ce_given = losses.cross_entropy_to_codes(flat, codes, given, cb.metric, live)
+            if training and want_loss and use_ce:
+                target = idx_view[..., 0]
+                if flat_mask is not None:
+                    target = target.masked_fill(~flat_mask, -1)
+                commit_loss = losses.cross_entropy_to_codes(flat, codes, target, cb.metric, live)
+            if training and self.has_codebook_diversity_loss and not return_loss:
+                row_id = torch.arange(flat.shape[1], device=flat.device)
+                position = (row_id % n) if (self.separate_codebook_per_head or heads == 1) else (row_id // heads) % n
+                diversity_loss = losses.codebook_diversity_loss(flat, codes, cb.metric, self.codebook_diversity_temperature,
+                                                                position, n, live)
+                loss = loss + diversity_loss * self.codebook_diversity_loss_weight
         if want_loss:
             loss = loss + commit_loss * self.commitment_weight
 
-        if training and cb.ema_update and not freeze_codebook:
+        if will_update:
             cb.ema_step(flat.detach(), idx, flat_mask)
+
+        if return_loss:
+            # the reference returns here, before heads are merged / projected back (vector_quantize_pytorch.py:298)
+            if self.separate_codebook_per_head and heads > 1:
+                quantize = out.reshape(heads, batch, n, head_dim)
+            elif heads > 1:
+                quantize = out.reshape(batch, n, heads, head_dim).permute(0, 2, 1, 3).reshape(1, batch * heads, n, head_dim)
+            else:
+                quantize = out.reshape(batch, n, head_dim)
+            return quantize, ce_given
+
+        ind_rows = i_buf.view(rows, heads)
+        if training and want_loss and use_ce and mask is not None:
+            ind_rows = ind_rows.masked_fill(~per_row[:, None], -1)  # the reference fills in place (vector_quantize_pytorch.py:344)
+
+        if training and self.has_codebook_orthogonal_loss:
+            # the fork reads a non-existent ``_codebook.embed`` here (vector_quantize_pytorch.py:367); repaired
+            codes = cb.embeddings
+            if self.orthogonal_reg_active_codes_only:
+                assert not (heads > 1 and self.separate_codebook_per_head), (
+                    "orthogonal regularization for only active codes not compatible with multi-headed with "
+                    "separate codebooks yet"
+                )
+                used = torch.unique(ind_rows)
+                codes = codes[:, used[used >= 0]]
+            num_codes = codes.shape[-2]
+            if self.orthogonal_reg_max_codes is not None and num_codes > self.orthogonal_reg_max_codes:
+                pick = torch.randperm(num_codes, device=codes.device)[: self.orthogonal_reg_max_codes]
+                codes = codes[:, pick]
+            orthogonal_loss = losses.orthogonal_loss(codes)
+            loss = loss + orthogonal_loss * self.orthogonal_reg_weight
 
         # ---- view the results back: rows are (b, n[, h]) ordered in both head modes
         if self.separate_codebook_per_head:
             quantize = out.permute(1, 0, 2).reshape(batch, n, heads * head_dim)  # a view when `out` is q_buf's
         else:
             quantize = out.reshape(batch, n, heads * head_dim)
-        embed_ind = i_buf.view(batch, n, heads)
+        embed_ind = ind_rows.view(batch, n, heads)
         if heads == 1:
             embed_ind = embed_ind[..., 0]
             embed_ind = embed_ind.reshape(batch, *spatial)
@@ -241,4 +298,4 @@ class VectorQuantize(nn.Module):
 
         if not return_loss_breakdown:
             return quantize, embed_ind, loss
-        return quantize, embed_ind, loss, LossBreakdown(commit_loss, self.zero, self.zero, self.zero)
+        return quantize, embed_ind, loss, LossBreakdown(commit_loss, diversity_loss, orthogonal_loss, self.zero)

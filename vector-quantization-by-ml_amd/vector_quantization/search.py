@@ -26,12 +26,23 @@ class _NativeBackend:
                             stages_share_codebook=share, out=out, idx=idx)
         return r["out"], r["idx"], r["best"], r["sq_err"]
 
+    @staticmethod
+    def similarities(x, cb, *, metric, out=None):
+        """x [H, M, D], cb [H, K, D] -> [H, M, K]  (vq_similarities_f32)."""
+        return native.similarities(x, cb.contiguous(), metric=metric, out=out)
+
+    @staticmethod
+    def softmax_stats(x, cb, *, metric, scale, target=None):
+        """-> (logsumexp_k scale * sim [H, M], logit of target [H, M] | None)  (vq_softmax_stats_f32)."""
+        return native.softmax_stats(x, cb.contiguous(), metric=metric, scale=scale, target=target)
+
 
 _backend = _NativeBackend
 
 
 def set_backend(backend) -> None:
-    """Install a different backend object exposing ``quantize`` (used by the CPU-only host-logic tests)."""
+    """Install a different backend object exposing ``quantize`` / ``similarities`` / ``softmax_stats`` (used by the
+    CPU-only host-logic tests)."""
     global _backend
     _backend = backend if backend is not None else _NativeBackend
 
