@@ -1,0 +1,69 @@
+"""Timing of the similarity-consuming entry points at the cfg2 shape (diagnostic; not the bench of record).
+
+    python tools/loss_bench.py            # on the GPU box
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vector-quantization-by-ml_amd"))
+
+import vector_quantization as vq  # noqa: E402
+from vector_quantization import native  # noqa: E402
+from vector_quantization.codebooks import CodebookParams  # noqa: E402
+
+
+def timed(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    dev = "cuda:0"
+    M, K, D = 262144, 1024, 256
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn((1, M, D), device=dev, generator=g)
+    cb = torch.randn((1, K, D), device=dev, generator=g)
+    tgt = torch.randint(0, K, (1, M), device=dev, generator=g)
+    packed = native.pack_codebooks(cb, 0)
+    flops = 2.0 * M * K * D
+    t = timed(lambda: native.quantize(x, cb[:, None], packed=packed, want_best=False))
+    print(f"search (reference point)        {t:8.3f} ms  {flops / t / 1e9:7.1f} TFLOP/s")
+    t = timed(lambda: native.softmax_stats(x, cb, target=tgt, packed=packed))
+    print(f"softmax stats (CE forward)      {t:8.3f} ms  {flops / t / 1e9:7.1f} TFLOP/s")
+    out = torch.empty((1, 65536, K), device=dev)
+    t = timed(lambda: native.similarities(x[:, :65536], cb, packed=packed, out=out))
+    print(f"similarities, 65536-row chunk   {t:8.3f} ms  {flops / 4 / t / 1e9:7.1f} TFLOP/s  {out.numel() * 4 / t / 1e6:7.1f} GB/s written")
+
+    mod = vq.VectorQuantize(dim=D, codebook_params=CodebookParams(dim=D, codebook_size=K),
+                            commitment_use_cross_entropy_loss=True).to(dev).train()
+    xs = torch.randn(256, 1024, D, device=dev, requires_grad=True)
+
+    def step():
+        xs.grad = None
+        q, i, loss = mod(xs, freeze_codebook=True)
+        loss.sum().backward()
+
+    t = timed(step, n=3, warm=1)
+    print(f"VectorQuantize CE commitment, forward + backward (train, frozen codebook)  {t:8.2f} ms")
+
+    def fwd():
+        with torch.no_grad():
+            mod(xs, freeze_codebook=True)
+
+    t = timed(fwd, n=5, warm=2)
+    print(f"VectorQuantize CE commitment, forward only                                 {t:8.2f} ms")
+
+
+if __name__ == "__main__":
+    main()
