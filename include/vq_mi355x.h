@@ -148,6 +148,17 @@ int vq_similarities_f32(const vq_args *a, float *sims, int64_t sims_rs, int64_t 
 int vq_softmax_stats_f32(const vq_args *a, float scale, const int64_t *target, int64_t tgt_rs, int64_t tgt_hs, float *lse,
                          float *target_logit, void *stream);
 
+/*
+ * Backward of that cross entropy with respect to x, fused (flash-attention style, nothing of [M, K] in memory):
+ *   grad_x[h, m, :] = coef * d/dx (lse - logit[target])   for rows with target >= 0, 0 for ignored rows
+ * = the autograd of F.cross_entropy o (-cdist | einsum) the reference runs -- vector_quantize_pytorch.py:292-294 with
+ * ATen's _euclidean_dist_backward.  lse: the vq_softmax_stats_f32 output (scale 1); coef: ONE float on the device
+ * (upstream gradient / number of non-ignored rows).  D <= 256 (VQ_E_UNSUPPORTED beyond: use row chunks of
+ * vq_similarities_f32).  Gradient with respect to the codebook is not produced.
+ */
+int vq_ce_backward_f32(const vq_args *a, const float *lse, const int64_t *target, int64_t tgt_rs, int64_t tgt_hs,
+                       const float *coef, float *grad_x, int64_t gx_rs, int64_t gx_hs, void *stream);
+
 const char *vq_last_error(void);
 int vq_device_info(char *buf, size_t n); /* "gfx950 ... CUs" of the current device */
 

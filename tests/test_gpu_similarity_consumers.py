@@ -130,3 +130,55 @@ def test_softmax_stats_cross_entropy_full_size():
         sims = native.similarities(x[:, r0:r0 + 8192], cb)
         acc += float(torch.nn.functional.cross_entropy(sims[0].double(), target[0, r0:r0 + 8192], reduction="sum"))
     assert abs(ce - acc / M) <= 1e-5 * max(1.0, abs(ce))
+
+
+def _ce_grad_reference(x, cb, target, metric, coef):
+    """float64 autograd of coef * sum_valid (lse - logit[target]) on the CPU."""
+    xd = x.double().clone().requires_grad_(True)
+    cd = cb.double()
+    sims = -torch.cdist(xd, cd) if metric == 0 else xd @ cd.transpose(-1, -2)
+    ce = torch.nn.functional.cross_entropy(sims.reshape(-1, sims.shape[-1]), target.reshape(-1), ignore_index=-1,
+                                           reduction="sum")
+    (coef * ce).backward()
+    return xd.grad
+
+
+@pytest.mark.parametrize("H,M,K,D", [s for s in SHAPES if s[3] <= 256])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_fused_cross_entropy_backward(H, M, K, D, metric):
+    """vq_ce_backward_f32 against float64 autograd; tolerance 2e-5 of the largest gradient entry."""
+    native = _native()
+    x, cb = make_x((H, M, D), "S"), make_codebook(H, K, D, "S")
+    if metric == 1:
+        x = x * 0.25  # keep the dot-product softmax away from one-hot saturation
+    g = torch.Generator().manual_seed(11)
+    target = torch.randint(0, K, (H, M), generator=g)
+    target[:, ::5] = -1
+    # make one row coincide with a code: dist == 0 -> subgradient 0 for that code (ATen masks res == 0)
+    if metric == 0 and M > 3:
+        x[0, 3] = cb[0, K // 2]
+    coef = 0.37
+    want = _ce_grad_reference(x, cb, target, metric, coef)
+    xs, cbs, ts = x.cuda(), cb.cuda(), target.cuda()
+    lse, _ = native.softmax_stats(xs, cbs, metric=metric, target=ts)
+    got = native.ce_backward(xs, cbs, lse, ts, torch.tensor([coef], device="cuda"), metric=metric)
+    torch.cuda.synchronize()
+    scale = max(float(want.abs().max()), coef)  # K == 1: the exact gradient is 0, fp32 leaves 1e-7 of noise
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), atol=2e-5 * scale, rtol=2e-4)
+    assert bool((got[:, ::5] == 0).all()), "ignored rows must get exactly zero gradient"
+
+
+def test_fused_cross_entropy_backward_strided_heads():
+    native = _native()
+    rows, heads, d, K = 200, 3, 32, 96
+    x4 = make_x((rows, heads, d), "S")
+    cb = make_codebook(heads, K, d, "S")
+    g = torch.Generator().manual_seed(2)
+    target = torch.randint(0, K, (rows, heads), generator=g)
+    flat = x4.cuda().permute(1, 0, 2)
+    ts = target.cuda().permute(1, 0)  # strided [h, rows]
+    lse, _ = native.softmax_stats(flat, cb.cuda(), target=ts)
+    got = native.ce_backward(flat, cb.cuda(), lse, ts, torch.tensor([1.0 / rows], device="cuda"))
+    want = _ce_grad_reference(x4.permute(1, 0, 2).contiguous(), cb, target.permute(1, 0).contiguous(), 0, 1.0 / rows)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), atol=2e-5 * float(want.abs().max()), rtol=2e-4)

@@ -978,6 +978,208 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_sweep_aux(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused cross-entropy backward:  d/dx of  coef * sum_rows (logsumexp_k sim - sim[target])
+//   S sweep      t[code, row] exactly as in the search (codes on the MFMA i axis, rows on j)
+//   epilogue     p = exp(sim - lse[row]);  gs = coef * (p - [code == target])            (d loss / d sim)
+//                Euclid: ratio = gs / sim (0 where sim == 0)   -- ATen _euclidean_dist_backward with dist = -sim
+//   G sweep      the 16 accumulator registers of the S sweep are, as they stand, valid B operands of
+//                v_mfma_f32_32x32x2_f32 for the second contraction (register r of the two lane halves = one k-pair of
+//                codes), so  G[pos, row] += Cimg[code, pos] * ratio[code, row]  needs no shuffles: Dp/2 more MFMAs per
+//                sub-tile, A fragments read from the SAME LDS tile (one ds_read_b128 feeds 4 MFMAs, "virtual" d-chunks
+//                of stride 4).
+//   finalize     Euclid: gx = x * sum_k ratio + 0.5 * G   (the image holds -2c);   dot: gx = G.   G is staged through
+//                LDS to undo the fragment / even-odd layout and written with coalesced stores.
+// Register budget: Dp/2 (x fragments) + Dp/2 (G accumulators) + ~60 -> 4-wave workgroups; Dp = 256 runs one wave per
+// SIMD (512 registers), Dp <= 128 two.  Dp = 512 is not supported (the caller falls back to row chunks).
+// ------------------------------------------------------------------------------------------------
+struct CeBwdParams {
+    const float *x;
+    long long x_rs, x_hs;
+    const float *packed;
+    long long pk_hs;
+    unsigned pk_bytes;
+    long long M;
+    int K, D, ntiles, vec_x;
+    const float *lse;  // [H * M]
+    const long long *target;
+    long long tgt_rs, tgt_hs;
+    const float *coef;  // one float on the device: upstream gradient / number of non-ignored rows
+    float *gx;
+    long long gx_rs, gx_hs;
+};
+
+template <int DP>
+struct CeGeo {
+    static constexpr int V = DP >= 128 ? 4 : DP / 32;  // floats per A-fragment read (positions 4i+e / 2i+e / i)
+    static constexpr int NJ = DP / (32 * V);           // 128-wide (V = 4) position blocks
+    static constexpr int NACC = DP / 32;               // 32x32 accumulators of G
+    static constexpr int GS = DP + 1;                  // staging row stride (floats): conflict-free column writes
+};
+
+template <int DP, int METRIC>
+__global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const CeBwdParams p) {
+    constexpr int WAVES = 4;
+    using G = Geo<DP, WAVES>;
+    using CG = CeGeo<DP>;
+    constexpr int RS = G::RS, RS4 = G::RS4, SUB = G::SUB, NG = DP / 8, V = CG::V, NJ = CG::NJ, NACC = CG::NACC;
+    constexpr bool EUCLID = (METRIC == VQ_METRIC_EUCLID);
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4 *tile4 = (f32x4 *)smem;
+    lds_f32x4 *tile4_lds = (lds_f32x4 *)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y;
+    const long long row0 = ((long long)blockIdx.x * WAVES + wave) * 32;
+    const float *xh = p.x + (long long)head * p.x_hs;
+
+    float xf[DP / 2];
+    float xn0;
+    load_x_fragments<DP, WAVES, EUCLID>(xh, p.x_rs, p.M, p.D, p.vec_x, row0, smem, wave, lane, xf, xn0);
+
+    const long long row = row0 + c;
+    const bool row_ok = row < p.M;
+    const float *pk = p.packed + (long long)head * p.pk_hs;
+    const float b_aug = h ? 1.0f : xn0;
+
+    int tgt = -1;
+    float lse2 = 0.0f;  // lse * log2(e)
+    if (row_ok) {
+        const long long tv = p.target[(long long)head * p.tgt_hs + row * p.tgt_rs];
+        tgt = (tv >= 0 && tv < p.K) ? (int)tv : -1;
+        lse2 = p.lse[(long long)head * p.M + row] * LOG2E;
+    }
+    const float coef_row = (tgt >= 0) ? p.coef[0] : 0.0f;  // ignored / padding rows contribute nothing
+    const int tgt_u = (tgt >= 0 && ((tgt >> 2) & 1) == h) ? (tgt >> 5) : -1;
+    const int tgt_r = (tgt & 3) + 4 * ((tgt >> 3) & 3);
+
+    f32x16 gacc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) gacc[j] = (f32x16){0};
+    float sum_ratio = 0.0f;
+
+    auto stage = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < (G::TILE_CHUNKS + WAVES - 1) / WAVES; ++i) {
+            const int ck = i * WAVES + wave;
+            if (ck < G::TILE_CHUNKS)
+                lds_dma16(pk, p.pk_bytes, lane * 16, (tile * G::TILE_F4 + ck * 64) * 16,
+                          tile4_lds + buf * G::BUF_F4 + ck * 64);
+        }
+    };
+
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < p.ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < p.ntiles) stage(t + 1, cur ^ 1);
+#pragma unroll 1
+        for (int st = 0; st < SUB; ++st) {
+            const int u = t * SUB + st;
+            if (u * kTileCodes >= p.K) break;  // workgroup-uniform
+            const f32x4 *tb = tile4 + cur * G::BUF_F4 + st * (kTileCodes * RS4);
+            // ---- S sweep
+            f32x16 acc = {0};
+            {
+                const f32x4 *ta = tb + c * RS4 + h;
+                f32x4 a[NG];
+                const float cnv = EUCLID ? ((const float *)tb)[c * RS + DP] : 0.0f;
+                mfma_prefetch<DP>(a, ta);
+                mfma_range<DP, 0, NG>(acc, a, ta, xf);
+                if (EUCLID) {
+                    const float a_aug = h ? cnv : 1.0f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug, acc, 0, 0, 0);
+                }
+            }
+            // ---- epilogue: acc[r] <- ratio (Euclid) / d loss / d sim (dot) of code u*32 + 4h + (r&3) + 8(r>>2)
+            const int cbase = u * kTileCodes + 4 * h;
+            const bool tail = u * kTileCodes + kTileCodes > p.K;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float tv = acc[r];
+                const float hit = (u == tgt_u && r == tgt_r) ? 1.0f : 0.0f;
+                float v;
+                if (EUCLID) {
+                    const float tc = fmaxf(tv, 0.0f);
+                    const float rs = __builtin_amdgcn_rsqf(tc);                      // 1 / dist
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(-(tc * rs), LOG2E, -lse2));  // exp(-dist - lse)
+                    v = -coef_row * (pr - hit) * rs;                                 // gs / sim,  sim = -dist
+                    v = (tc > 0.0f) ? v : 0.0f;                                      // subgradient 0 at dist == 0
+                } else {
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(tv, LOG2E, -lse2));
+                    v = coef_row * (pr - hit);
+                }
+                if (tail && cbase + (r & 3) + 8 * (r >> 2) >= p.K) v = 0.0f;
+                acc[r] = v;
+                if (EUCLID) sum_ratio += v;
+            }
+            // ---- G sweep: gacc[J*V + e][pos-in-chunk i, row] += Cimg[code(r, half)][128J + 4i + e] * acc[r]
+            const float *trow = (const float *)tb + (4 * h) * RS + V * c;
+#pragma unroll
+            for (int J = 0; J < NJ; ++J) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float *ap = trow + ((r & 3) + 8 * (r >> 2)) * RS + 32 * V * J;
+                    if (V == 4) {
+                        const f32x4 a4 = *(const f32x4 *)ap;
+                        gacc[J * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, acc[r], gacc[J * 4 + 0], 0, 0, 0);
+                        gacc[J * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, acc[r], gacc[J * 4 + 1], 0, 0, 0);
+                        gacc[J * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, acc[r], gacc[J * 4 + 2], 0, 0, 0);
+                        gacc[J * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, acc[r], gacc[J * 4 + 3], 0, 0, 0);
+                    } else if (V == 2) {
+                        const float a0 = ap[0], a1 = ap[1];
+                        gacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, acc[r], gacc[0], 0, 0, 0);
+                        gacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, acc[r], gacc[1], 0, 0, 0);
+                    } else {
+                        gacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[0], acc[r], gacc[0], 0, 0, 0);
+                    }
+                    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the fragment reads in flight
+                }
+            }
+        }
+        __syncthreads();  // next tile landed, everybody is done reading this one
+    }
+
+    // ---------------- finalize: fragment layout -> natural rows through LDS ----------------
+    // (the loop's last barrier guarantees nobody reads the tile buffers any more)
+    constexpr int GS = CG::GS;
+    float *stg = smem + wave * (32 * GS + 32);
+    float *srs = stg + 32 * GS;
+    if (EUCLID) {
+        sum_ratio += __shfl_xor(sum_ratio, 32);
+        if (h == 0) srs[c] = sum_ratio;
+    }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        const int J = a / V, e = a % V;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 8 * (r >> 2) + 4 * h + (r & 3);       // MFMA i index held by this lane's register r
+            const int pos = 32 * V * J + V * i + e;             // position in the packed row
+            const int p8 = pos & 7;
+            const int dim = (pos & ~7) + (p8 < 4 ? 2 * p8 : 2 * (p8 - 4) + 1);
+            stg[c * GS + dim] = gacc[a][r];
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-order LDS, no barrier needed
+    const int nrows = (p.M - row0 >= 32) ? 32 : (int)(p.M - row0);
+    float *gxh = p.gx + (long long)head * p.gx_hs;
+    for (int rr = 0; rr < nrows; ++rr) {
+        const float sr = EUCLID ? srs[rr] : 0.0f;
+        const float *xr = xh + (row0 + rr) * p.x_rs;
+        float *gr = gxh + (row0 + rr) * p.gx_rs;
+        for (int d = lane; d < p.D; d += 64) {
+            const float gv = stg[rr * GS + d];
+            gr[d] = EUCLID ? fmaf(xr[d], sr, 0.5f * gv) : gv;
+        }
+    }
+}
+
 // scalar fallback for the similarity matrix (D > 512, cross-check): one thread per (row, code)
 template <int METRIC>
 __global__ void __launch_bounds__(256) vq_sims_simple(const float *__restrict__ x, long long x_rs, long long x_hs,
@@ -1328,6 +1530,32 @@ int launch_aux(int DP, const AuxParams &p, int H, int metric, int mode, hipStrea
         case 512: return launch_aux_m<512, 4>(p, H, metric, mode, s);
     }
     return fail(VQ_E_UNSUPPORTED, "vq_sweep_aux: unsupported padded dim");
+}
+
+
+template <int DP, int METRIC>
+int launch_ce_bwd_t(const CeBwdParams &p, int H, hipStream_t s) {
+    using G = Geo<DP, 4>;
+    const size_t stage_floats = (size_t)4 * (32 * CeGeo<DP>::GS + 32);
+    const size_t lds = 4 * ((size_t)G::MAIN_FLOATS > stage_floats ? (size_t)G::MAIN_FLOATS : stage_floats);
+    auto kern = vq_ce_backward<DP, METRIC>;
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+        attr_done = true;
+    }
+    dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)H, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_ce_backward launch");
+    return 0;
+}
+
+template <int DP>
+int launch_ce_bwd_m(const CeBwdParams &p, int H, int metric, hipStream_t s) {
+    if (metric == VQ_METRIC_EUCLID) return launch_ce_bwd_t<DP, VQ_METRIC_EUCLID>(p, H, s);
+    return launch_ce_bwd_t<DP, VQ_METRIC_DOT>(p, H, s);
 }
 
 bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -1694,6 +1922,36 @@ int vq_softmax_stats_f32(const vq_args *a, float scale, const int64_t *target, i
     p.target = (const long long *)target; p.tgt_rs = tgt_rs; p.tgt_hs = tgt_hs;
     p.lse = lse; p.tgt_logit = target_logit;
     return launch_aux(DP, p, a->H, a->metric, kAuxStats, (hipStream_t)stream);
+}
+
+int vq_ce_backward_f32(const vq_args *a, const float *lse, const int64_t *target, int64_t tgt_rs, int64_t tgt_hs,
+                       const float *coef, float *grad_x, int64_t gx_rs, int64_t gx_hs, void *stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (a->M == 0) return 0;
+    if (!lse || !target || !coef || !grad_x) return fail(VQ_E_BADARG, "vq_ce_backward: null argument");
+    const int DP = padded_dim(a->D);
+    if (DP == 0 || DP > 256) return fail(VQ_E_UNSUPPORTED, "vq_ce_backward: D > 256 (use vq_similarities_f32 row chunks)");
+    AuxParams ap;
+    rc = fill_aux_params(ap, a, "vq_ce_backward");
+    if (rc) return rc;
+    CeBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = ap.x; p.x_rs = ap.x_rs; p.x_hs = ap.x_hs;
+    p.packed = ap.packed; p.pk_hs = ap.pk_hs; p.pk_bytes = ap.pk_bytes;
+    p.M = ap.M; p.K = ap.K; p.D = ap.D; p.ntiles = ap.ntiles; p.vec_x = ap.vec_x;
+    p.lse = lse;
+    p.target = (const long long *)target; p.tgt_rs = tgt_rs; p.tgt_hs = tgt_hs;
+    p.coef = coef;
+    p.gx = grad_x; p.gx_rs = gx_rs; p.gx_hs = gx_hs;
+    hipStream_t s = (hipStream_t)stream;
+    switch (DP) {
+        case 32: return launch_ce_bwd_m<32>(p, a->H, a->metric, s);
+        case 64: return launch_ce_bwd_m<64>(p, a->H, a->metric, s);
+        case 128: return launch_ce_bwd_m<128>(p, a->H, a->metric, s);
+        case 256: return launch_ce_bwd_m<256>(p, a->H, a->metric, s);
+    }
+    return fail(VQ_E_UNSUPPORTED, "vq_ce_backward: unsupported padded dim");
 }
 
 int vq_nearest_f32(const vq_args *a, void *stream) {

@@ -116,6 +116,8 @@ def load():
         lib.vq_similarities_f32.restype = ctypes.c_int
         lib.vq_softmax_stats_f32.argtypes = [ap, ctypes.c_float, _vp, _i64, _i64, _vp, _vp, _vp]
         lib.vq_softmax_stats_f32.restype = ctypes.c_int
+        lib.vq_ce_backward_f32.argtypes = [ap, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]
+        lib.vq_ce_backward_f32.restype = ctypes.c_int
         lib.vq_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         lib.vq_device_info.restype = ctypes.c_int
         _lib = lib
@@ -126,6 +128,7 @@ EXPORTED_SYMBOLS = (
     "vq_packed_floats", "vq_pack_codebooks_f32", "vq_workspace_bytes", "vq_quantize_f32", "vq_nearest_f32",
     "vq_residual_f32", "vq_keys_init", "vq_search_keys_f32", "vq_finalize_keys_f32", "vq_last_error",
     "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32", "vq_similarities_f32", "vq_softmax_stats_f32",
+    "vq_ce_backward_f32",
 )
 
 
@@ -398,3 +401,25 @@ def softmax_stats(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, sc
                                            tl.data_ptr() if tl is not None else None, _stream_ptr(dev)),
                "vq_softmax_stats_f32")
     return lse, tl
+
+
+CE_BACKWARD_MAX_DIM = 256
+
+
+def ce_backward(x: torch.Tensor, cb: torch.Tensor, lse: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, *,
+                metric: int = EUCLID, packed: torch.Tensor | None = None) -> torch.Tensor:
+    """Fused backward of the cross entropy over the codebook: grad_x [H, M, D] = coef * d/dx (lse - logit[target]) for
+    rows with target >= 0 (0 otherwise).  lse [H, M] from softmax_stats (scale 1), coef: 1-element fp32 device tensor."""
+    a, packed = _aux_args(x, cb, metric, packed, 0)
+    H, M, D = x.shape
+    _require_gpu(lse, target, coef)
+    assert D <= CE_BACKWARD_MAX_DIM
+    assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (H, M)
+    assert target.dtype == torch.int64 and tuple(target.shape) == (H, M)
+    assert coef.dtype == torch.float32 and coef.numel() == 1
+    gx = torch.empty((H, M, D), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(load().vq_ce_backward_f32(ctypes.byref(a), lse.data_ptr(), target.data_ptr(), int(target.stride(1)),
+                                         int(target.stride(0)), coef.data_ptr(), gx.data_ptr(), D, M * D,
+                                         _stream_ptr(x.device)), "vq_ce_backward_f32")
+    return gx

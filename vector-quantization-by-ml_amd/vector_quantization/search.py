@@ -37,6 +37,14 @@ class _NativeBackend:
         return native.softmax_stats(x, cb.contiguous(), metric=metric, scale=scale, target=target)
 
 
+    @staticmethod
+    def cross_entropy_backward(x, cb, lse, target, coef, *, metric):
+        """Fused d/dx of the cross entropy (vq_ce_backward_f32); None when the shape is outside the kernel's range."""
+        if x.shape[-1] > native.CE_BACKWARD_MAX_DIM:
+            return None
+        return native.ce_backward(x, cb.contiguous(), lse, target, coef, metric=metric)
+
+
 _backend = _NativeBackend
 
 
