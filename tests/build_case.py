@@ -67,7 +67,7 @@ def build(case, arrays=None, device="cpu"):
         shared = case.get("shared_codebook", False)
         mod = vq.ResidualVQ(dim=dim, num_quantizers=Q,
                             codebook_params=CodebookParams(dim=dim, codebook_size=K, **case.get("cb_extra", {})),
-                            shared_codebook=shared)
+                            shared_codebook=shared, **case.get("vq_extra", {}))
         cb = make_rvq_codebooks(Q, K, dim, case["cls"])
         with torch.no_grad():
             for i, layer in enumerate(mod.layers):

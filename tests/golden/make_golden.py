@@ -216,7 +216,8 @@ def run_rvq(ref, ref_cb, c):
     dim, K, Q = c["dim"], c["K"], c["Q"]
     params = ref_cb.CodebookParams(dim=dim, codebook_size=K, **c.get("cb_extra", {}))
     shared = c.get("shared_codebook", False)
-    mod = ref.ResidualVQ(dim=dim, num_quantizers=Q, codebook_params=params, shared_codebook=shared)
+    mod = ref.ResidualVQ(dim=dim, num_quantizers=Q, codebook_params=params, shared_codebook=shared,
+                         **c.get("vq_extra", {}))
     cbs = make_rvq_codebooks(Q, K, dim, c["cls"])
     with torch.no_grad():
         for i, layer in enumerate(mod.layers):

@@ -118,7 +118,10 @@ class ResidualVQ(nn.Module):
                     or cb.transform_input.__name__ != "_identity"
                     or cb.metric != cb0.metric or cb.embeddings.shape != cb0.embeddings.shape
                     or layer.commitment_weight != first.commitment_weight
-                    or cb.learnable_codebook):
+                    or cb.learnable_codebook
+                    # losses that look at the similarities go through VectorQuantize.forward layer by layer
+                    or layer.commitment_use_cross_entropy_loss or layer.has_codebook_diversity_loss
+                    or layer.has_codebook_orthogonal_loss):
                 return False
         return True
 
