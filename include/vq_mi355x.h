@@ -153,7 +153,7 @@ int vq_softmax_stats_f32(const vq_args *a, float scale, const int64_t *target, i
  *   grad_x[h, m, :] = coef * d/dx (lse - logit[target])   for rows with target >= 0, 0 for ignored rows
  * = the autograd of F.cross_entropy o (-cdist | einsum) the reference runs -- vector_quantize_pytorch.py:292-294 with
  * ATen's _euclidean_dist_backward.  lse: the vq_softmax_stats_f32 output (scale 1); coef: ONE float on the device
- * (upstream gradient / number of non-ignored rows).  D <= 256 (VQ_E_UNSUPPORTED beyond: use row chunks of
+ * (upstream gradient / number of non-ignored rows).  D <= 512 (VQ_E_UNSUPPORTED beyond: use row chunks of
  * vq_similarities_f32).  Gradient with respect to the codebook is not produced.
  */
 int vq_ce_backward_f32(const vq_args *a, const float *lse, const int64_t *target, int64_t tgt_rs, int64_t tgt_hs,

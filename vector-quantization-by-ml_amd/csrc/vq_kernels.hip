@@ -991,7 +991,8 @@ __global__ void __launch_bounds__(WAVES * 64, (DP <= 256 ? 2 : 1)) vq_sweep_aux(
 //   finalize     Euclid: gx = x * sum_k ratio + 0.5 * G   (the image holds -2c);   dot: gx = G.   G is staged through
 //                LDS to undo the fragment / even-odd layout and written with coalesced stores.
 // Register budget: Dp/2 (x fragments) + Dp/2 (G accumulators) + ~60 -> 4-wave workgroups; Dp = 256 runs one wave per
-// SIMD (512 registers), Dp <= 128 two.  Dp = 512 is not supported (the caller falls back to row chunks).
+// SIMD (512 registers), Dp <= 128 two.  Dp = 512: two workgroups per row block (blockIdx.z), each repeats the S sweep
+// and produces one 256-wide half of the dims (3 instead of 2 units of MFMA work).
 // ------------------------------------------------------------------------------------------------
 struct CeBwdParams {
     const float *x;
@@ -1012,9 +1013,12 @@ struct CeBwdParams {
 template <int DP>
 struct CeGeo {
     static constexpr int V = DP >= 128 ? 4 : DP / 32;  // floats per A-fragment read (positions 4i+e / 2i+e / i)
-    static constexpr int NJ = DP / (32 * V);           // 128-wide (V = 4) position blocks
-    static constexpr int NACC = DP / 32;               // 32x32 accumulators of G
-    static constexpr int GS = DP + 1;                  // staging row stride (floats): conflict-free column writes
+    static constexpr int NH = DP > 256 ? DP / 256 : 1; // the G accumulators of Dp = 512 do not fit beside the x fragments:
+                                                       // blockIdx.z picks a 256-wide half of the packed positions
+    static constexpr int WID = DP / NH;                // positions (= dims) one workgroup produces
+    static constexpr int NJ = WID / (32 * V);          // 128-wide (V = 4) position blocks
+    static constexpr int NACC = WID / 32;              // 32x32 accumulators of G
+    static constexpr int GS = WID + 1;                 // staging row stride (floats): conflict-free column writes
 };
 
 template <int DP, int METRIC>
@@ -1023,7 +1027,9 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
     using G = Geo<DP, WAVES>;
     using CG = CeGeo<DP>;
     constexpr int RS = G::RS, RS4 = G::RS4, SUB = G::SUB, NG = DP / 8, V = CG::V, NJ = CG::NJ, NACC = CG::NACC;
+    constexpr int WID = CG::WID;
     constexpr bool EUCLID = (METRIC == VQ_METRIC_EUCLID);
+    const int pos0 = (CG::NH > 1) ? (int)blockIdx.z * WID : 0;  // first packed position (= dim) of this workgroup
     constexpr float LOG2E = 1.4426950408889634f;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1119,7 +1125,7 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
                 if (EUCLID) sum_ratio += v;
             }
             // ---- G sweep: gacc[J*V + e][pos-in-chunk i, row] += Cimg[code(r, half)][128J + 4i + e] * acc[r]
-            const float *trow = (const float *)tb + (4 * h) * RS + V * c;
+            const float *trow = (const float *)tb + (4 * h) * RS + V * c + pos0;
 #pragma unroll
             for (int J = 0; J < NJ; ++J) {
 #pragma unroll
@@ -1160,7 +1166,7 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 8 * (r >> 2) + 4 * h + (r & 3);       // MFMA i index held by this lane's register r
-            const int pos = 32 * V * J + V * i + e;             // position in the packed row
+            const int pos = 32 * V * J + V * i + e;             // position in this workgroup's part of the packed row
             const int p8 = pos & 7;
             const int dim = (pos & ~7) + (p8 < 4 ? 2 * p8 : 2 * (p8 - 4) + 1);
             stg[c * GS + dim] = gacc[a][r];
@@ -1173,8 +1179,9 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
         const float sr = EUCLID ? srs[rr] : 0.0f;
         const float *xr = xh + (row0 + rr) * p.x_rs;
         float *gr = gxh + (row0 + rr) * p.gx_rs;
-        for (int d = lane; d < p.D; d += 64) {
-            const float gv = stg[rr * GS + d];
+        for (int dl = lane; dl < WID && pos0 + dl < p.D; dl += 64) {
+            const int d = pos0 + dl;
+            const float gv = stg[rr * GS + dl];
             gr[d] = EUCLID ? fmaf(xr[d], sr, 0.5f * gv) : gv;
         }
     }
@@ -1545,7 +1552,7 @@ int launch_ce_bwd_t(const CeBwdParams &p, int H, hipStream_t s) {
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
         attr_done = true;
     }
-    dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)H, 1);
+    dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)H, (unsigned)CeGeo<DP>::NH);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "vq_ce_backward launch");
@@ -1931,7 +1938,7 @@ int vq_ce_backward_f32(const vq_args *a, const float *lse, const int64_t *target
     if (a->M == 0) return 0;
     if (!lse || !target || !coef || !grad_x) return fail(VQ_E_BADARG, "vq_ce_backward: null argument");
     const int DP = padded_dim(a->D);
-    if (DP == 0 || DP > 256) return fail(VQ_E_UNSUPPORTED, "vq_ce_backward: D > 256 (use vq_similarities_f32 row chunks)");
+    if (DP == 0) return fail(VQ_E_UNSUPPORTED, "vq_ce_backward: D > 512 (use vq_similarities_f32 row chunks)");
     AuxParams ap;
     rc = fill_aux_params(ap, a, "vq_ce_backward");
     if (rc) return rc;
@@ -1950,6 +1957,7 @@ int vq_ce_backward_f32(const vq_args *a, const float *lse, const int64_t *target
         case 64: return launch_ce_bwd_m<64>(p, a->H, a->metric, s);
         case 128: return launch_ce_bwd_m<128>(p, a->H, a->metric, s);
         case 256: return launch_ce_bwd_m<256>(p, a->H, a->metric, s);
+        case 512: return launch_ce_bwd_m<512>(p, a->H, a->metric, s);
     }
     return fail(VQ_E_UNSUPPORTED, "vq_ce_backward: unsupported padded dim");
 }

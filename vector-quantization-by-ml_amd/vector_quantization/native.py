@@ -403,7 +403,7 @@ def softmax_stats(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, sc
     return lse, tl
 
 
-CE_BACKWARD_MAX_DIM = 256
+CE_BACKWARD_MAX_DIM = 512
 
 
 def ce_backward(x: torch.Tensor, cb: torch.Tensor, lse: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, *,
