@@ -30,3 +30,40 @@ check(64, 100, 1000, 16)              # many heads, tiny M
 check(3, 50_000, 5000, 200, metric=1) # padded D, dot
 check(1, 300, 40, 512)                # Dp = 512 small
 check(2, 10_000, 300, 384)            # D padded to 512
+
+
+def check_aux(H, M, K, D, sample=256, metric=0):
+    """similarity consumers at awkward sizes: emitted matrix (sampled rows) vs oracle, stats and fused backward vs fp64."""
+    g = torch.Generator().manual_seed(H * 11 + K)
+    x = torch.randn((H, M, D), generator=g) * (0.2 if metric else 1.0)
+    cb = torch.randn((H, K, D), generator=g)
+    tgt = torch.randint(0, K, (H, M), generator=g)
+    tgt[:, ::9] = -1
+    xs, cbs, ts = x.to(dev), cb.to(dev), tgt.to(dev)
+    lse, tl = native.softmax_stats(xs, cbs, metric=metric, target=ts)
+    gx = native.ce_backward(xs, cbs, lse, ts, torch.tensor([0.5], device=dev), metric=metric) if D <= 512 else None
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.randperm(M, generator=g)[:sample], torch.tensor([0, M - 1])])
+    ok = True
+    for h in range(min(H, 2)):
+        sims = native.similarities(xs[h:h + 1, rows].contiguous(), cbs[h:h + 1], metric=metric)[0].cpu()
+        ok &= bool(np.array_equal(sims.numpy(), o.similarities(x[h, rows].numpy(), cb[h].numpy(), metric)))
+        xd = x[h, rows].double().requires_grad_(True)
+        sd = -torch.cdist(xd, cb[h].double()) if metric == 0 else xd @ cb[h].double().T
+        ok &= bool(torch.allclose(lse[h, rows].cpu().double(), torch.logsumexp(sd, -1).detach(), rtol=3e-6, atol=3e-5))
+        ce = torch.nn.functional.cross_entropy(sd, tgt[h, rows], ignore_index=-1, reduction="sum") * 0.5
+        ce.backward()
+        if gx is not None:
+            scale = max(float(xd.grad.abs().max()), 0.5)
+            ok &= bool((gx[h, rows].cpu().double() - xd.grad).abs().max() <= 3e-5 * scale)
+    print(f"aux H={H} M={M} K={K} D={D} metric={metric}: {'OK' if ok else 'MISMATCH'}")
+    torch.cuda.empty_cache()
+
+
+check_aux(1, 1_000_001, 256, 64)
+check_aux(1, 4000, 65_536, 512)        # cfg5 codebook, Dp = 512 (two half-dim workgroups)
+check_aux(1, 777, 100_003, 32)         # large odd K
+check_aux(48, 100, 1000, 16)           # many heads
+check_aux(3, 20_000, 5000, 200, metric=1)
+check_aux(2, 5_000, 300, 384)          # D padded to 512
+check_aux(1, 129, 33, 250)             # D padded to 256, one partial block

@@ -1795,6 +1795,9 @@ int vq_quantize_f32(const vq_args *a, void *stream) {
             waves = 4;
             wgs = (long long)a->H * ((a->M + 127) / 128);
         }
+#ifdef VQ_EXP_WAVES
+        waves = VQ_EXP_WAVES;  // diagnostic builds only
+#endif
         const int ntiles = (a->K + kTileCodes * sub_tiles(DP) - 1) / (kTileCodes * sub_tiles(DP));
         // few workgroups and a long sweep: splitting K over workgroups fills the chip (Q == 1 only)
         if (a->Q == 1 && wgs * 2 <= cus && ntiles * sub_tiles(DP) >= 8 && ntiles >= 2) fused = false;
