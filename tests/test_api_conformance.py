@@ -213,3 +213,72 @@ def test_random_projection_quantizer(device):
     assert agree > 0.99, agree  # fp32 summation order may flip exact near-ties only
     picked = torch.gather(sims, -1, idx[..., None])[..., 0]
     torch.testing.assert_close(picked, sims.max(-1).values, rtol=0, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- stochastic sampling
+def _stochastic_codebook(K, d, temperature, device):
+    from vector_quantization.codebooks import Codebook, GumbelParams
+
+    torch.manual_seed(1)
+    cb = Codebook(dim=d, codebook_size=K, gumbel_params=GumbelParams(stochastic=True, temperature=temperature)).to(device)
+    with torch.no_grad():
+        cb.embeddings.copy_(torch.randn(1, K, d))
+    return cb
+
+
+def test_stochastic_sampling_limits_and_seed(device):
+    """Gumbel-max code sampling (utils/general.py:106-129) is RNG-dependent -- no parity with the reference's draws --
+    so it is pinned by its properties: temperature -> 0 is the deterministic argmax, equal seeds give equal draws."""
+    from vector_quantization import search
+
+    K, d = 64, 16
+    x = torch.randn(1, 500, d, device=device)
+    cold = _stochastic_codebook(K, d, 1e-6, device).eval()
+    q, ind, _ = cold(x)
+    det, _, _ = search.nearest_with_distance(x.reshape(1, -1, d), cold.embeddings)
+    assert torch.equal(ind.reshape(-1), det.reshape(-1))
+    assert torch.equal(q, cold.embeddings[0][ind])
+    warm = _stochastic_codebook(K, d, 1.0, device).eval()  # eval: no EMA update between the calls; sampling stays on
+    torch.manual_seed(7)
+    a = warm(x)[1]
+    torch.manual_seed(7)
+    b = warm(x)[1]
+    torch.manual_seed(8)
+    c = warm(x)[1]
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_stochastic_sampling_follows_the_softmax(device):
+    """20000 copies of one row: code frequencies ~ softmax(similarities / temperature) (5 sigma)."""
+    K, d, n, temp = 8, 4, 20000, 0.7
+    cb = _stochastic_codebook(K, d, temp, device)
+    row = torch.randn(1, 1, d, device=device) * 0.5
+    x = row.expand(1, n, d).contiguous()
+    torch.manual_seed(3)
+    _, ind, sims = cb(x, return_similarities=True)
+    prob = (sims[0, 0, 0] / temp).softmax(-1).double().cpu()
+    freq = torch.bincount(ind.reshape(-1).cpu(), minlength=K).double() / n
+    sigma = (prob * (1 - prob) / n).sqrt()
+    assert bool(((freq - prob).abs() <= 5 * sigma + 1e-4).all()), (freq, prob)
+
+
+def test_stochastic_in_vector_quantize_and_residual(device):
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams, GumbelParams
+
+    params = CodebookParams(dim=8, codebook_size=32, gumbel_params=GumbelParams(stochastic=True))
+    torch.manual_seed(0)
+    mod = vq.VectorQuantize(dim=8, codebook_params=params).to(device).train()
+    x = torch.randn(2, 50, 8, device=device, requires_grad=True)
+    q, ind, loss = mod(x, freeze_codebook=True)
+    assert q.shape == x.shape and ind.shape == (2, 50) and loss.shape == (1,)
+    torch.testing.assert_close(q, mod._codebook.embeddings[0][ind])  # straight-through value == the sampled code
+    (q.sum() + loss.sum()).backward()
+    codes = mod._codebook.embeddings[0][ind]
+    torch.testing.assert_close(x.grad, 1.0 + 2.0 * (x.detach() - codes) / x.numel(), rtol=1e-5, atol=1e-6)
+    rvq = vq.ResidualVQ(dim=8, num_quantizers=3, shared_codebook=True, codebook_params=params).to(device)
+    out, idx, losses, codes_all = rvq(x.detach(), return_all_codes=True)
+    assert out.shape == x.shape and idx.shape == (2, 50, 3) and losses.shape == (1, 3) and codes_all.shape == (3, 2, 50, 8)
+    with pytest.raises(NotImplementedError):
+        vq.VectorQuantize(dim=8, codebook_params=CodebookParams(
+            dim=8, codebook_size=32, gumbel_params=GumbelParams(stochastic=True, straight_through=True))).to(device)(x)

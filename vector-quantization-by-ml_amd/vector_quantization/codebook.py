@@ -126,8 +126,10 @@ class Codebook(nn.Module):
 
     # ------------------------------------------------------------------ helpers
     def _stochastic_requested(self) -> bool:
+        """The reference always samples through ``sample_fn_training`` (codebooks.py:388), whose ``training`` flag is
+        GumbelParams.training (default True) -- NOT the module's train / eval state."""
         g = self.gumbel_params
-        return bool(self.training and g.get("stochastic", False) and g.get("temperature", 1.0) > 0)
+        return bool(g.get("training", True) and g.get("stochastic", False) and g.get("temperature", 1.0) > 0)
 
     def _sync_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.use_ddp and dist.is_available() and dist.is_initialized():
@@ -142,13 +144,46 @@ class Codebook(nn.Module):
                       codebook_grad_from_err: bool = False, out=None, idx=None):
         """flat [h, M, D] (strided rows fine) -> (out [h, M, D], idx [h, M] int64, sq_err [1] float64 | None)."""
         if self._stochastic_requested():
-            raise NotImplementedError("stochastic (Gumbel) code sampling is RNG-dependent and not part of the "
-                                      "native deterministic search (SURVEY 2, #4)")
+            return self._quantize_stochastic(flat, ste=ste, want_sq_err=want_sq_err,
+                                             codebook_grad_from_err=codebook_grad_from_err, idx=idx)
         codes = self.current_codes()
         out, idx, sq_err = search.quantize_rows(flat, codes[:, None], metric=self.metric, ste=ste,
                                                 want_sq_err=want_sq_err,
                                                 codebook_grad_from_err=codebook_grad_from_err, out=out, idx=idx)
         return out, idx[..., 0], sq_err
+
+    def _quantize_stochastic(self, flat, *, ste, want_sq_err, codebook_grad_from_err, idx=None):
+        """Gumbel-max sampling of the code (utils/general.py:106-129): ind = argmax(similarities / temperature + g),
+        g = -log(-log(u)).  RNG-dependent, so no parity with the reference's draws is possible; the similarities come
+        from the native kernel in bounded row chunks and the noise from torch's generator on the tensor's device.
+        Straight-through / reinmax relaxations (gradients through the softmax) are not provided."""
+        from . import losses
+
+        g = self.gumbel_params
+        if g.get("straight_through", False) or g.get("reinmax", False):
+            raise NotImplementedError("straight-through / reinmax Gumbel relaxations are outside the MI355X hot-path "
+                                      "build (SURVEY 2, #4); plain stochastic sampling is supported")
+        codes = self.current_codes()
+        h, m, _ = flat.shape
+        x = flat.float()
+        step = losses._rows_per_chunk(h, self.codebook_size)
+        ind = torch.empty((h, m), dtype=torch.int64, device=flat.device)
+        eps = 1e-5  # the reference's log(t) clamps at 1e-5 (utils/general.py:25-26)
+        with torch.no_grad():
+            for r0 in range(0, m, step):
+                sims = losses.similarity_matrix(x[:, r0:r0 + step].detach(), codes.detach(), self.metric)
+                noise = torch.zeros_like(sims).uniform_(0, 1)
+                gumbel = -(-noise.clamp(min=eps).log()).clamp(min=eps).log()
+                ind[:, r0:r0 + step] = (sims / g.get("temperature", 1.0) + gumbel).argmax(dim=-1)
+        if idx is not None:
+            idx.copy_(ind[..., None])
+        picked = codes[torch.arange(h, device=flat.device)[:, None], ind]  # [h, m, d]; differentiable w.r.t. a learnable codebook
+        sq_err = None
+        if want_sq_err:
+            target = picked if codebook_grad_from_err else picked.detach()
+            sq_err = ((target - x) ** 2).sum(dtype=torch.float64).reshape(1)
+        out = x + (picked - x).detach() if ste else picked
+        return out, ind, sq_err
 
     def similarities(self, flat: torch.Tensor) -> torch.Tensor:
         """The [h, M, K] matrix the reference returns on every call (codebooks.py:386,435), on demand
