@@ -82,6 +82,33 @@ class ShardedCodebookSearch:
             dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
         return keys
 
+    def quantize_local_rows(self, x_local: torch.Tensor, *, ste: bool = False, want_sq_err: bool = False):
+        """Data-parallel callers: every rank holds ITS OWN rows x_local [M_local, D] (same M_local on all ranks) and
+        wants them quantized against the whole sharded codebook ("tokens start rank-local").
+
+        all-gather the rows (M_local * D * 4 B per rank) -> every rank searches its shard for ALL rows ->
+        reduce-scatter(MIN) of the packed keys, so each rank receives exactly the reduced keys of its own rows
+        (8 B per row on the wire) -> local finalize.  Needs the replicated gather table (``full_codebook``).
+        -> (quantized [M_local, D], idx [M_local] GLOBAL, best [M_local], sq_err | None) for this rank's rows."""
+        x_local = x_local.float().contiguous()
+        if self.world == 1:
+            return self(x_local, ste=ste, want_sq_err=want_sq_err)
+        assert self.full is not None, "quantize_local_rows needs full_codebook for the local gather"
+        m_local, d = x_local.shape
+        rows = torch.empty((self.world * m_local, d), dtype=torch.float32, device=x_local.device)
+        dist.all_gather_into_tensor(rows, x_local, group=self.group)
+        if self.packed is not None:
+            keys = self.ops.local_keys(rows, self.shard, self.metric, self.rank * self.k_local, self.packed)
+        else:
+            keys = self.ops.local_keys(rows, self.shard, self.metric, self.rank * self.k_local)
+        mine = torch.empty((m_local,), dtype=torch.int64, device=x_local.device)
+        try:
+            dist.reduce_scatter_tensor(mine, keys, op=dist.ReduceOp.MIN, group=self.group)
+        except (RuntimeError, NotImplementedError):  # backends without reduce-scatter (gloo): all-reduce, keep our slice
+            dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
+            mine = keys[self.rank * m_local:(self.rank + 1) * m_local].contiguous()
+        return self.ops.finalize(x_local, self.full, mine, self.metric, ste, want_sq_err)
+
     def __call__(self, x: torch.Tensor, *, ste: bool = False, want_sq_err: bool = False):
         """-> (quantized [M, D], idx [M] int64 GLOBAL indices, best [M], sq_err | None)."""
         x = x.float()
