@@ -13,6 +13,11 @@ def make_mask(b, n):
     return mask
 
 
+def q_weights(shape):
+    """Same seeded weights as tests/golden/make_golden.py:q_weights."""
+    return torch.randn(tuple(shape), generator=torch.Generator().manual_seed(4242))
+
+
 def given_indices(case, shape, K):
     """Same seeded teacher-forcing targets as tests/golden/make_golden.py:given_indices."""
     g = torch.Generator().manual_seed(99)
@@ -41,9 +46,12 @@ def build(case, arrays=None, device="cpu"):
                                 transform_input=case.get("transform_input", "identity"),
                                 weights_regularization=case.get("weights_regularization", "identity"),
                                 **case.get("cb_extra", {}))
+        extra = dict(case.get("vq_extra", {}))
+        if "inplace_sgd_lr" in case:
+            extra["in_place_codebook_optimizer"] = lambda params: torch.optim.SGD(params, lr=case["inplace_sgd_lr"])
         mod = vq.VectorQuantize(dim=dim, codebook_params=params, codebook_dim=codebook_dim, heads=heads,
                                 separate_codebook_per_head=separate, channel_last=case.get("channel_last", True),
-                                **case.get("vq_extra", {}))
+                                **extra)
         cb = make_codebook(h, K, d, case["cls"])
         if case.get("weights_regularization", "identity") == "l2norm":
             cb = l2norm(cb)

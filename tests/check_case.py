@@ -90,7 +90,12 @@ def compare_loss(case, arrays, meta, mod, x, kwargs):
         np.testing.assert_array_equal(idx.detach().cpu().numpy(), arrays["idx"].astype(np.int64))
         got_b = np.asarray([float(v.detach()) for v in breakdown], dtype=np.float32)
         np.testing.assert_allclose(got_b, arrays["breakdown"], rtol=1e-5 * amp, atol=1e-5 * amp)
-    loss.sum().backward()
+    objective = loss.sum()
+    if case.get("backprop_q", False):
+        from build_case import q_weights
+
+        objective = objective + (q * q_weights(q.shape).to(q.device)).sum()
+    objective.backward()
     np.testing.assert_allclose(loss.detach().cpu().numpy(), arrays["loss"], rtol=1e-5 * amp, atol=1e-5 * amp)
     assert list(q.shape) == meta["q_shape"], (q.shape, meta["q_shape"])
     flat_q = q.detach().cpu().reshape(-1, q.shape[-1]).numpy()
@@ -106,6 +111,9 @@ def compare_loss(case, arrays, meta, mod, x, kwargs):
     if "ema_embeddings" in arrays:
         np.testing.assert_allclose(mod._codebook.embeddings.detach().cpu().numpy(), arrays["ema_embeddings"], rtol=1e-4,
                                    atol=1e-5)
+    if "cb_grad" in arrays:
+        cg = mod._codebook.embeddings.grad.detach().cpu().numpy()
+        np.testing.assert_allclose(cg, arrays["cb_grad"], rtol=1e-4, atol=1e-5 * max(1e-12, float(np.abs(arrays["cb_grad"]).max())))
     s = float(grad.double().abs().sum())
     assert abs(s - meta["g_checksum"][1]) <= 1e-4 * amp * max(1e-12, meta["g_checksum"][1]), (s, meta["g_checksum"])
     return float(loss.detach().sum())

@@ -137,4 +137,17 @@ LOSS_CASES = [
          cb_extra=dict(threshold_ema_dead_code=0)),
 ]
 
+_LEARN = dict(learnable_codebook=True, ema_update=False)
+
+LOSS_CASES += [
+    # --- learnable codebook options of the quantize step: gradient scaling rule and the in-place optimizer ------------
+    _vql("learnable", 64, 256, (4, 64, 64), cb_extra=_LEARN, freeze_codebook=False, backprop_q=True),
+    _vql("sync_update", 64, 256, (4, 64, 64), cb_extra=_LEARN, freeze_codebook=False, backprop_q=True,
+         vq_extra=dict(sync_update_v=0.5)),
+    _vql("inplace_sgd", 64, 256, (4, 64, 64), cb_extra=_LEARN, freeze_codebook=False, backprop_q=True, inplace_sgd_lr=50.0),
+    _vql("inplace_sgd_mask", 32, 64, (3, 40, 32), cb_extra=_LEARN, freeze_codebook=False, mask=True, inplace_sgd_lr=20.0),
+    _vql("inplace_sgd_mh", 64, 128, (2, 50, 64), cb_extra=_LEARN, freeze_codebook=False, heads=2, codebook_dim=32,
+         separate_codebook_per_head=True, inplace_sgd_lr=50.0),
+]
+
 LOSS_CASES_BY_NAME = {c["name"]: c for c in LOSS_CASES}

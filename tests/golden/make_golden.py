@@ -125,6 +125,11 @@ def run_vq(ref, ref_cb, c):
     return arrays, meta
 
 
+def q_weights(shape):
+    """Seeded weights for the cases that also backpropagate through the quantized output."""
+    return torch.randn(tuple(shape), generator=torch.Generator().manual_seed(4242))
+
+
 def given_indices(c, rows_shape, K):
     """Teacher-forcing targets for the ``indices=`` cases (seeded; shared with tests/build_case.py)."""
     g = torch.Generator().manual_seed(99)
@@ -148,8 +153,11 @@ def run_vqloss(ref, ref_cb, c):
         transform_input=c.get("transform_input", "identity"),
         weights_regularization=c.get("weights_regularization", "identity"), **c.get("cb_extra", {}))
     torch.manual_seed(777)
+    extra = dict(c.get("vq_extra", {}))
+    if "inplace_sgd_lr" in c:
+        extra["in_place_codebook_optimizer"] = lambda params: torch.optim.SGD(params, lr=c["inplace_sgd_lr"])
     mod = ref.VectorQuantize(dim=dim, codebook_params=params, codebook_dim=codebook_dim, heads=heads,
-                             separate_codebook_per_head=separate, channel_last=channel_last, **c.get("vq_extra", {}))
+                             separate_codebook_per_head=separate, channel_last=channel_last, **extra)
     assert not mod.has_projections
     cb = make_codebook(h, K, d, c["cls"])
     if c.get("weights_regularization", "identity") == "l2norm":
@@ -178,7 +186,10 @@ def run_vqloss(ref, ref_cb, c):
         q, idx, loss, breakdown = mod(x, return_loss_breakdown=True, **kwargs)
         arrays["idx"] = idx.numpy().astype(np.int32)
         arrays["breakdown"] = np.asarray([float(v) for v in breakdown], dtype=np.float32)
-    loss.sum().backward()
+    objective = loss.sum()
+    if c.get("backprop_q", False):
+        objective = objective + (q * q_weights(q.shape)).sum()
+    objective.backward()
     grad = x.grad.detach()
     arrays["loss"] = loss.detach().numpy().astype(np.float32)
     arrays["q_shape"] = np.asarray(q.shape, dtype=np.int64)
@@ -192,6 +203,8 @@ def run_vqloss(ref, ref_cb, c):
         arrays["g_full"] = grad.numpy().copy()
     if c["training"] and not c.get("freeze_codebook", True):
         arrays["ema_embeddings"] = mod._codebook.embeddings.detach().numpy().copy()
+        if mod._codebook.embeddings.grad is not None:
+            arrays["cb_grad"] = mod._codebook.embeddings.grad.detach().numpy().copy()
     meta = dict(x_checksum=checksum(x.detach()), cb_checksum=checksum(cb), q_checksum=checksum(q.detach()),
                 g_checksum=checksum(grad), q_shape=list(q.shape))
     return arrays, meta

@@ -88,11 +88,6 @@ class VectorQuantize(nn.Module):
             "learnable codebook must be turned on"
         )
         self.sync_update_v = sync_update_v
-        if sync_update_v > 0.0:
-            raise NotImplementedError("synchronous update rule (sync_update_v) is outside the hot-path build")
-        if in_place_codebook_optimizer is not None:
-            raise NotImplementedError("in_place_codebook_optimizer is outside the hot-path build")
-        self.in_place_codebook_optimizer = None
 
         if sync_codebook is None:
             sync_codebook = _world_is_distributed()
@@ -105,6 +100,10 @@ class VectorQuantize(nn.Module):
         )
         self.learnable_codebook = codebook_params.learnable_codebook
         self._codebook = Codebook(**asdict(self.codebook_params))
+        # vector_quantize_pytorch.py:130-134: a factory that is handed the codebook's parameters
+        self.in_place_codebook_optimizer = (
+            in_place_codebook_optimizer(self._codebook.parameters()) if in_place_codebook_optimizer is not None else None
+        )
         self.register_buffer("zero", torch.tensor(0.0), persistent=False)
 
     # ------------------------------------------------------------------ codebook access (repaired w.r.t. the fork)
@@ -195,8 +194,23 @@ class VectorQuantize(nn.Module):
             cb.is_initialized = True
 
         loss = torch.zeros(1, device=x.device, dtype=torch.float32)
-        commit_loss = diversity_loss = orthogonal_loss = self.zero
+        commit_loss = diversity_loss = orthogonal_loss = inplace_loss = self.zero
         cb_grad_from_err = self.learnable_codebook and not freeze_codebook
+        will_update = training and cb.ema_update and not freeze_codebook
+
+        if self.in_place_codebook_optimizer is not None and training and not freeze_codebook:
+            # vector_quantize_pytorch.py:234-259: one optimizer step on mse(quantize, x) with respect to the codebook,
+            # then the codebook is searched again.  Only the search is needed from the first pass.
+            with torch.no_grad():
+                _, first_idx, _ = cb.quantize_flat(flat.detach())
+            picked = cb.current_codes()[torch.arange(flat.shape[0], device=flat.device)[:, None], first_idx]
+            err = (picked - flat.detach()) ** 2
+            inplace_loss = err[flat_mask].mean() if flat_mask is not None else err.mean()
+            inplace_loss.backward()
+            self.in_place_codebook_optimizer.step()
+            self.in_place_codebook_optimizer.zero_grad()
+            if will_update:  # the reference's first Codebook.forward already ran its EMA step
+                cb.ema_step(flat.detach(), first_idx, flat_mask)
         if mask is None:
             # the one native launch: search + gather + straight-through + squared error
             out, idx, sq_err = cb.quantize_flat(flat, ste=training, want_sq_err=want_sq_err,
@@ -210,10 +224,12 @@ class VectorQuantize(nn.Module):
                 commit_loss = ((target - flat) ** 2)[flat_mask].mean()
             if training:
                 out = flat + (out - flat).detach()
+        if training and self.sync_update_v > 0.0:
+            # eq. (21) of the vqtorch draft (vector_quantize_pytorch.py:275-279): same value, gradient scaled by 1 + v
+            out = out + self.sync_update_v * (out - out.detach())
 
         # ---- consumers of the similarity matrix (rare): evaluated against the codebook the search
         #      used, i.e. BEFORE the EMA step below rewrites it
-        will_update = training and cb.ema_update and not freeze_codebook
         needs_sims = return_loss or (training and ((want_loss and use_ce) or self.has_codebook_diversity_loss))
         if needs_sims:
             codes, live = cb.current_codes(), None
@@ -298,4 +314,4 @@ class VectorQuantize(nn.Module):
 
         if not return_loss_breakdown:
             return quantize, embed_ind, loss
-        return quantize, embed_ind, loss, LossBreakdown(commit_loss, diversity_loss, orthogonal_loss, self.zero)
+        return quantize, embed_ind, loss, LossBreakdown(commit_loss, diversity_loss, orthogonal_loss, inplace_loss)
