@@ -9,11 +9,19 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "vector-quantization-by-ml_amd")]
 import torch, numpy as np
 from vector_quantization import native
 M, K, D = (int(v) for v in sys.argv[1].split(","))
+BWD = len(sys.argv) > 2 and sys.argv[2] == "bwd"  # stamps of vq_ce_backward (4-wave workgroups) instead of the search
 dev = torch.device("cuda:0"); g = torch.Generator().manual_seed(0)
 x = torch.randn((1, M, D), generator=g).to(dev); cb = torch.randn((1, 1, K, D), generator=g).to(dev)
 packed = native.pack_codebooks(cb, 0)
-for _ in range(3):
-    native.quantize(x, cb, packed=packed, want_best=False)
+if BWD:
+    tgt = torch.randint(0, K, (1, M), generator=g).to(dev)
+    lse, _ = native.softmax_stats(x, cb[:, 0], target=tgt, packed=packed)
+    coef = torch.tensor([1.0 / M], device=dev)
+    for _ in range(3):
+        native.ce_backward(x, cb[:, 0], lse, tgt, coef, packed=packed)
+else:
+    for _ in range(3):
+        native.quantize(x, cb, packed=packed, want_best=False)
 torch.cuda.synchronize()
 lib = native.load()
 buf = (ctypes.c_uint64 * (8192 * 4))()

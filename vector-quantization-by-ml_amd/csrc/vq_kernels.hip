@@ -791,8 +791,8 @@ __device__ __forceinline__ void load_x_fragments(const float *xh, long long x_rs
     constexpr int NCHUNK = DP / CH;
     constexpr int LPL = CH / 8;
     xn0 = 0.0f;
-#pragma unroll
-    for (int ch = 0; ch < NCHUNK; ++ch) {
+    f32x4 v[2][LPL];  // global loads of chunk i+1 are in flight while chunk i goes through LDS
+    auto load_chunk = [&](int ch, f32x4 (&dst)[LPL]) {
 #pragma unroll
         for (int it = 0; it < LPL; ++it) {
             const int f = it * 64 + lane;
@@ -810,7 +810,18 @@ __device__ __forceinline__ void load_x_fragments(const float *xh, long long x_rs
                 if (d0 + 2 < D) t.z = src[2];
                 if (d0 + 3 < D) t.w = src[3];
             }
-            *(f32x4 *)(xs + r * XS + c4 * 4) = t;
+            dst[it] = t;
+        }
+    };
+    load_chunk(0, v[0]);
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        if (ch + 1 < NCHUNK) load_chunk(ch + 1, v[(ch + 1) & 1]);
+#pragma unroll
+        for (int it = 0; it < LPL; ++it) {
+            const int f = it * 64 + lane;
+            const int r = f / (CH / 4), c4 = f % (CH / 4);
+            *(f32x4 *)(xs + r * XS + c4 * 4) = v[ch & 1][it];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const float *rp = xs + c * XS;
@@ -1018,7 +1029,7 @@ struct CeGeo {
     static constexpr int WID = DP / NH;                // positions (= dims) one workgroup produces
     static constexpr int NJ = WID / (32 * V);          // 128-wide (V = 4) position blocks
     static constexpr int NACC = WID / 32;              // 32x32 accumulators of G
-    static constexpr int GS = WID + 1;                 // staging row stride (floats): conflict-free column writes
+    static constexpr int GS = WID + 4;                 // staging row stride (floats): 16-B aligned rows, 2-way conflicts on the column writes
 };
 
 template <int DP, int METRIC>
@@ -1044,9 +1055,11 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
     const long long row0 = ((long long)blockIdx.x * WAVES + wave) * 32;
     const float *xh = p.x + (long long)head * p.x_hs;
 
+    STAMP(0);
     float xf[DP / 2];
     float xn0;
     load_x_fragments<DP, WAVES, EUCLID>(xh, p.x_rs, p.M, p.D, p.vec_x, row0, smem, wave, lane, xf, xn0);
+    STAMP(1);
 
     const long long row = row0 + c;
     const bool row_ok = row < p.M;
@@ -1126,18 +1139,31 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
             }
             // ---- G sweep: gacc[J*V + e][pos-in-chunk i, row] += Cimg[code(r, half)][128J + 4i + e] * acc[r]
             const float *trow = (const float *)tb + (4 * h) * RS + V * c + pos0;
+            if constexpr (V == 4) {
+                // fragment reads run PF steps ahead of their MFMAs, order pinned (same scheme as mfma_range)
+                constexpr int NSEQ = NJ * 16, PF = 4;
+                auto frag = [&](int n) -> f32x4 {
+                    const int J = n >> 4, r = n & 15;
+                    return *(const f32x4 *)(trow + ((r & 3) + 8 * (r >> 2)) * RS + 128 * J);
+                };
+                f32x4 af[NSEQ];
 #pragma unroll
-            for (int J = 0; J < NJ; ++J) {
+                for (int n = 0; n < PF; ++n) af[n] = frag(n);
+#pragma unroll
+                for (int n = 0; n < NSEQ; ++n) {
+                    if (n + PF < NSEQ) af[n + PF] = frag(n + PF);
+                    const int J = n >> 4, r = n & 15;
+                    gacc[J * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[n].x, acc[r], gacc[J * 4 + 0], 0, 0, 0);
+                    gacc[J * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[n].y, acc[r], gacc[J * 4 + 1], 0, 0, 0);
+                    gacc[J * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[n].z, acc[r], gacc[J * 4 + 2], 0, 0, 0);
+                    gacc[J * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[n].w, acc[r], gacc[J * 4 + 3], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float *ap = trow + ((r & 3) + 8 * (r >> 2)) * RS + 32 * V * J;
-                    if (V == 4) {
-                        const f32x4 a4 = *(const f32x4 *)ap;
-                        gacc[J * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, acc[r], gacc[J * 4 + 0], 0, 0, 0);
-                        gacc[J * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, acc[r], gacc[J * 4 + 1], 0, 0, 0);
-                        gacc[J * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, acc[r], gacc[J * 4 + 2], 0, 0, 0);
-                        gacc[J * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, acc[r], gacc[J * 4 + 3], 0, 0, 0);
-                    } else if (V == 2) {
+                    const float *ap = trow + ((r & 3) + 8 * (r >> 2)) * RS;
+                    if (V == 2) {
                         const float a0 = ap[0], a1 = ap[1];
                         gacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, acc[r], gacc[0], 0, 0, 0);
                         gacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, acc[r], gacc[1], 0, 0, 0);
@@ -1151,6 +1177,7 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
         __syncthreads();  // next tile landed, everybody is done reading this one
     }
 
+    STAMP(2);
     // ---------------- finalize: fragment layout -> natural rows through LDS ----------------
     // (the loop's last barrier guarantees nobody reads the tile buffers any more)
     constexpr int GS = CG::GS;
@@ -1175,16 +1202,56 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-order LDS, no barrier needed
     const int nrows = (p.M - row0 >= 32) ? 32 : (int)(p.M - row0);
     float *gxh = p.gx + (long long)head * p.gx_hs;
-    for (int rr = 0; rr < nrows; ++rr) {
-        const float sr = EUCLID ? srs[rr] : 0.0f;
-        const float *xr = xh + (row0 + rr) * p.x_rs;
-        float *gr = gxh + (row0 + rr) * p.gx_rs;
-        for (int dl = lane; dl < WID && pos0 + dl < p.D; dl += 64) {
-            const int d = pos0 + dl;
-            const float gv = stg[rr * GS + dl];
-            gr[d] = EUCLID ? fmaf(xr[d], sr, 0.5f * gv) : gv;
+    const bool vec_g = p.vec_x && (p.gx_rs % 4 == 0) && (p.gx_hs % 4 == 0) && (((uintptr_t)p.gx & 15) == 0);
+    if (vec_g) {
+        constexpr int RB = 8;                      // rows in flight: the x loads are latency-bound
+        constexpr int NV = (WID + 255) / 256;      // float4 per lane and row
+        for (int rr0 = 0; rr0 < nrows; rr0 += RB) {
+            f32x4 xv[RB][NV];
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int rr = (rr0 + k < nrows) ? rr0 + k : nrows - 1;
+                const float *xr = xh + (row0 + rr) * p.x_rs + pos0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int dl = 4 * (lane + 64 * j);
+                    xv[k][j] = (dl < WID && pos0 + dl < p.D) ? *(const f32x4 *)(xr + dl) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                if (rr0 + k < nrows) {
+                    const float sr = EUCLID ? srs[rr0 + k] : 0.0f;
+                    float *gr = gxh + (row0 + rr0 + k) * p.gx_rs + pos0;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        const int dl = 4 * (lane + 64 * j);
+                        if (dl < WID && pos0 + dl < p.D) {
+                            const f32x4 gv = *(const f32x4 *)(stg + (rr0 + k) * GS + dl);
+                            f32x4 o;
+                            o.x = EUCLID ? fmaf(xv[k][j].x, sr, 0.5f * gv.x) : gv.x;
+                            o.y = EUCLID ? fmaf(xv[k][j].y, sr, 0.5f * gv.y) : gv.y;
+                            o.z = EUCLID ? fmaf(xv[k][j].z, sr, 0.5f * gv.z) : gv.z;
+                            o.w = EUCLID ? fmaf(xv[k][j].w, sr, 0.5f * gv.w) : gv.w;
+                            *(f32x4 *)(gr + dl) = o;
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        for (int rr = 0; rr < nrows; ++rr) {
+            const float sr = EUCLID ? srs[rr] : 0.0f;
+            const float *xr = xh + (row0 + rr) * p.x_rs;
+            float *gr = gxh + (row0 + rr) * p.gx_rs;
+            for (int dl = lane; dl < WID && pos0 + dl < p.D; dl += 64) {
+                const int d = pos0 + dl;
+                const float gv = stg[rr * GS + dl];
+                gr[d] = EUCLID ? fmaf(xr[d], sr, 0.5f * gv) : gv;
+            }
         }
     }
+    STAMP(3);
 }
 
 // scalar fallback for the similarity matrix (D > 512, cross-check): one thread per (row, code)
