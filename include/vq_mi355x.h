@@ -152,12 +152,14 @@ int vq_softmax_stats_f32(const vq_args *a, float scale, const int64_t *target, i
  * Backward of that cross entropy with respect to x, fused (flash-attention style, nothing of [M, K] in memory):
  *   grad_x[h, m, :] = coef * d/dx (lse - logit[target])   for rows with target >= 0, 0 for ignored rows
  * = the autograd of F.cross_entropy o (-cdist | einsum) the reference runs -- vector_quantize_pytorch.py:292-294 with
- * ATen's _euclidean_dist_backward.  lse: the vq_softmax_stats_f32 output (scale 1); coef: ONE float on the device
+ * ATen's _euclidean_dist_backward.  lse / target_logit: the vq_softmax_stats_f32 outputs (scale 1; the softmax part of
+ * the gradient runs through the MFMA sweep, the one-hot part is a rank-one term per row added from a->cb, the natural
+ * codebook, with 1 / dist_target taken from target_logit); coef: ONE float on the device
  * (upstream gradient / number of non-ignored rows).  D <= 512 (VQ_E_UNSUPPORTED beyond: use row chunks of
  * vq_similarities_f32).  Gradient with respect to the codebook is not produced.
  */
-int vq_ce_backward_f32(const vq_args *a, const float *lse, const int64_t *target, int64_t tgt_rs, int64_t tgt_hs,
-                       const float *coef, float *grad_x, int64_t gx_rs, int64_t gx_hs, void *stream);
+int vq_ce_backward_f32(const vq_args *a, const float *lse, const float *target_logit, const int64_t *target, int64_t tgt_rs,
+                       int64_t tgt_hs, const float *coef, float *grad_x, int64_t gx_rs, int64_t gx_hs, void *stream);
 
 const char *vq_last_error(void);
 int vq_device_info(char *buf, size_t n); /* "gfx950 ... CUs" of the current device */

@@ -160,8 +160,8 @@ def test_fused_cross_entropy_backward(H, M, K, D, metric):
     coef = 0.37
     want = _ce_grad_reference(x, cb, target, metric, coef)
     xs, cbs, ts = x.cuda(), cb.cuda(), target.cuda()
-    lse, _ = native.softmax_stats(xs, cbs, metric=metric, target=ts)
-    got = native.ce_backward(xs, cbs, lse, ts, torch.tensor([coef], device="cuda"), metric=metric)
+    lse, tl = native.softmax_stats(xs, cbs, metric=metric, target=ts)
+    got = native.ce_backward(xs, cbs, lse, tl, ts, torch.tensor([coef], device="cuda"), metric=metric)
     torch.cuda.synchronize()
     scale = max(float(want.abs().max()), coef)  # K == 1: the exact gradient is 0, fp32 leaves 1e-7 of noise
     np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), atol=2e-5 * scale, rtol=2e-4)
@@ -177,8 +177,8 @@ def test_fused_cross_entropy_backward_strided_heads():
     target = torch.randint(0, K, (rows, heads), generator=g)
     flat = x4.cuda().permute(1, 0, 2)
     ts = target.cuda().permute(1, 0)  # strided [h, rows]
-    lse, _ = native.softmax_stats(flat, cb.cuda(), target=ts)
-    got = native.ce_backward(flat, cb.cuda(), lse, ts, torch.tensor([1.0 / rows], device="cuda"))
+    lse, tl = native.softmax_stats(flat, cb.cuda(), target=ts)
+    got = native.ce_backward(flat, cb.cuda(), lse, tl, ts, torch.tensor([1.0 / rows], device="cuda"))
     want = _ce_grad_reference(x4.permute(1, 0, 2).contiguous(), cb, target.permute(1, 0).contiguous(), 0, 1.0 / rows)
     torch.cuda.synchronize()
     np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), atol=2e-5 * float(want.abs().max()), rtol=2e-4)

@@ -41,7 +41,7 @@ def check_aux(H, M, K, D, sample=256, metric=0):
     tgt[:, ::9] = -1
     xs, cbs, ts = x.to(dev), cb.to(dev), tgt.to(dev)
     lse, tl = native.softmax_stats(xs, cbs, metric=metric, target=ts)
-    gx = native.ce_backward(xs, cbs, lse, ts, torch.tensor([0.5], device=dev), metric=metric) if D <= 512 else None
+    gx = native.ce_backward(xs, cbs, lse, tl, ts, torch.tensor([0.5], device=dev), metric=metric) if D <= 512 else None
     torch.cuda.synchronize()
     rows = torch.cat([torch.randperm(M, generator=g)[:sample], torch.tensor([0, M - 1])])
     ok = True

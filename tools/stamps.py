@@ -15,10 +15,10 @@ x = torch.randn((1, M, D), generator=g).to(dev); cb = torch.randn((1, 1, K, D), 
 packed = native.pack_codebooks(cb, 0)
 if BWD:
     tgt = torch.randint(0, K, (1, M), generator=g).to(dev)
-    lse, _ = native.softmax_stats(x, cb[:, 0], target=tgt, packed=packed)
+    lse, tl = native.softmax_stats(x, cb[:, 0], target=tgt, packed=packed)
     coef = torch.tensor([1.0 / M], device=dev)
     for _ in range(3):
-        native.ce_backward(x, cb[:, 0], lse, tgt, coef, packed=packed)
+        native.ce_backward(x, cb[:, 0], lse, tl, tgt, coef, packed=packed)
 else:
     for _ in range(3):
         native.quantize(x, cb, packed=packed, want_best=False)

@@ -29,6 +29,7 @@
 
 #include "../../include/vq_mi355x.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1017,6 +1018,9 @@ struct CeBwdParams {
     const long long *target;
     long long tgt_rs, tgt_hs;
     const float *coef;  // one float on the device: upstream gradient / number of non-ignored rows
+    const float *cb;    // natural codebook (the target's term is added in the finalize)
+    long long cb_hs;
+    const float *tgt_logit;  // [H * M] similarity of the target code (vq_softmax_stats_f32 output, scale 1)
     float *gx;
     long long gx_rs, gx_hs;
 };
@@ -1068,14 +1072,16 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
 
     int tgt = -1;
     float lse2 = 0.0f;  // lse * log2(e)
+    float tlog = 0.0f;  // similarity of the target code
     if (row_ok) {
         const long long tv = p.target[(long long)head * p.tgt_hs + row * p.tgt_rs];
         tgt = (tv >= 0 && tv < p.K) ? (int)tv : -1;
         lse2 = p.lse[(long long)head * p.M + row] * LOG2E;
+        tlog = p.tgt_logit[(long long)head * p.M + row];
     }
     const float coef_row = (tgt >= 0) ? p.coef[0] : 0.0f;  // ignored / padding rows contribute nothing
-    const int tgt_u = (tgt >= 0 && ((tgt >> 2) & 1) == h) ? (tgt >> 5) : -1;
-    const int tgt_r = (tgt & 3) + 4 * ((tgt >> 3) & 3);
+    // The sweep below handles the softmax part  coef * p_k  of d loss / d sim_k for every code alike; the one-hot part
+    // (-coef at k = target) is a rank-one term per row and is added in the finalize from the natural codebook.
 
     f32x16 gacc[NACC];
 #pragma unroll
@@ -1116,26 +1122,59 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
                 }
             }
             // ---- epilogue: acc[r] <- ratio (Euclid) / d loss / d sim (dot) of code u*32 + 4h + (r&3) + 8(r>>2)
+            // (softmax part only; two values per step so that the multiplies / fma / add pack into v_pk_* instructions)
             const int cbase = u * kTileCodes + 4 * h;
             const bool tail = u * kTileCodes + kTileCodes > p.K;
+            bool degenerate = false;  // some squared distance <= 0: ATen gives those codes the subgradient 0
+            if (EUCLID) {
+                float tm = vmin3(acc[0], acc[1], acc[2]);
+                tm = vmin3(tm, acc[3], acc[4]);
+                tm = vmin3(tm, acc[5], acc[6]);
+                tm = vmin3(tm, acc[7], acc[8]);
+                tm = vmin3(tm, acc[9], acc[10]);
+                tm = vmin3(tm, acc[11], acc[12]);
+                tm = vmin3(tm, acc[13], acc[14]);
+                tm = fminf(tm, acc[15]);
+                degenerate = __any(tm <= 0.0f);
+            }
+            {
+                const f32x2 ncoef = {-coef_row, -coef_row}, pcoef = {coef_row, coef_row};
+                const f32x2 nl2e = {-LOG2E, -LOG2E}, pl2e = {LOG2E, LOG2E}, nlse = {-lse2, -lse2};
+                f32x2 sum2 = {0.0f, 0.0f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float tv = acc[r];
-                const float hit = (u == tgt_u && r == tgt_r) ? 1.0f : 0.0f;
-                float v;
-                if (EUCLID) {
-                    const float tc = fmaxf(tv, 0.0f);
-                    const float rs = __builtin_amdgcn_rsqf(tc);                      // 1 / dist
-                    const float pr = __builtin_amdgcn_exp2f(fmaf(-(tc * rs), LOG2E, -lse2));  // exp(-dist - lse)
-                    v = -coef_row * (pr - hit) * rs;                                 // gs / sim,  sim = -dist
-                    v = (tc > 0.0f) ? v : 0.0f;                                      // subgradient 0 at dist == 0
-                } else {
-                    const float pr = __builtin_amdgcn_exp2f(fmaf(tv, LOG2E, -lse2));
-                    v = coef_row * (pr - hit);
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 tv = {acc[r], acc[r + 1]};
+                    f32x2 v;
+                    if (EUCLID) {
+                        const f32x2 tc = {vmax3(tv.x, 0.0f, 0.0f), vmax3(tv.y, 0.0f, 0.0f)};
+                        const f32x2 rs = {__builtin_amdgcn_rsqf(tc.x), __builtin_amdgcn_rsqf(tc.y)};  // 1 / dist
+                        const f32x2 ex = __builtin_elementwise_fma(tc * rs, nl2e, nlse);               // (-dist - lse) log2 e
+                        const f32x2 pr = {__builtin_amdgcn_exp2f(ex.x), __builtin_amdgcn_exp2f(ex.y)};
+                        v = (pr * rs) * ncoef;  // gs / sim with sim = -dist; inf / nan where dist == 0 (fixed below)
+                    } else {
+                        const f32x2 ex = __builtin_elementwise_fma(tv, pl2e, nlse);
+                        const f32x2 pr = {__builtin_amdgcn_exp2f(ex.x), __builtin_amdgcn_exp2f(ex.y)};
+                        v = pr * pcoef;
+                    }
+                    acc[r] = v.x;
+                    acc[r + 1] = v.y;
+                    if (EUCLID) sum2 += v;
                 }
-                if (tail && cbase + (r & 3) + 8 * (r >> 2) >= p.K) v = 0.0f;
-                acc[r] = v;
-                if (EUCLID) sum_ratio += v;
+                float sum_u = sum2.x + sum2.y;
+                // rare wave-uniform fix-ups, kept out of the straight-line path: zero distances and the codebook's tail
+                if (degenerate || tail) {
+                    asm volatile("" ::: "memory");  // keep this a branch (16 selects per lane otherwise)
+                    sum_u = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[r];
+                        if (!(__builtin_fabsf(v) < __builtin_inff())) v = 0.0f;            // 1 / 0: subgradient 0
+                        if (cbase + (r & 3) + 8 * (r >> 2) >= p.K) v = 0.0f;               // padding codes
+                        acc[r] = v;
+                        sum_u += v;
+                    }
+                }
+                if (EUCLID) sum_ratio += sum_u;
             }
             // ---- G sweep: gacc[J*V + e][pos-in-chunk i, row] += Cimg[code(r, half)][128J + 4i + e] * acc[r]
             const float *trow = (const float *)tb + (4 * h) * RS + V * c + pos0;
@@ -1181,11 +1220,17 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
     // ---------------- finalize: fragment layout -> natural rows through LDS ----------------
     // (the loop's last barrier guarantees nobody reads the tile buffers any more)
     constexpr int GS = CG::GS;
-    float *stg = smem + wave * (32 * GS + 32);
+    float *stg = smem + wave * (32 * GS + 96);
     float *srs = stg + 32 * GS;
-    if (EUCLID) {
-        sum_ratio += __shfl_xor(sum_ratio, 32);
-        if (h == 0) srs[c] = sum_ratio;
+    // per row: sum of the ratios (Euclid) and the one-hot term's factor  f:  gx += f * (c_target - x)  (Euclid,
+    // f = -coef / dist_t = coef / sim_t, 0 at dist_t == 0)   or   gx += f * c_target  (dot, f = -coef)
+    int *stg_t = (int *)(srs + 32);
+    float *stg_f = srs + 64;
+    if (EUCLID) sum_ratio += __shfl_xor(sum_ratio, 32);
+    if (h == 0) {
+        srs[c] = sum_ratio;
+        stg_t[c] = tgt;
+        stg_f[c] = EUCLID ? ((tlog < 0.0f) ? coef_row / tlog : 0.0f) : -coef_row;
     }
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {
@@ -1202,37 +1247,51 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-order LDS, no barrier needed
     const int nrows = (p.M - row0 >= 32) ? 32 : (int)(p.M - row0);
     float *gxh = p.gx + (long long)head * p.gx_hs;
-    const bool vec_g = p.vec_x && (p.gx_rs % 4 == 0) && (p.gx_hs % 4 == 0) && (((uintptr_t)p.gx & 15) == 0);
+    const float *cbh = p.cb + (long long)head * p.cb_hs;
+    const bool vec_g = p.vec_x && (p.gx_rs % 4 == 0) && (p.gx_hs % 4 == 0) && (((uintptr_t)p.gx & 15) == 0) &&
+                       (p.cb_hs % 4 == 0) && (((uintptr_t)p.cb & 15) == 0);
     if (vec_g) {
-        constexpr int RB = 8;                      // rows in flight: the x loads are latency-bound
+        constexpr int RB = 8;                      // rows in flight: the x / codebook loads are latency-bound
         constexpr int NV = (WID + 255) / 256;      // float4 per lane and row
         for (int rr0 = 0; rr0 < nrows; rr0 += RB) {
-            f32x4 xv[RB][NV];
+            f32x4 xv[RB][NV], cv[RB][NV];
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
                 const int rr = (rr0 + k < nrows) ? rr0 + k : nrows - 1;
                 const float *xr = xh + (row0 + rr) * p.x_rs + pos0;
+                const int t = stg_t[rr];
+                const float *cr = cbh + (long long)(t < 0 ? 0 : t) * p.D + pos0;
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     const int dl = 4 * (lane + 64 * j);
-                    xv[k][j] = (dl < WID && pos0 + dl < p.D) ? *(const f32x4 *)(xr + dl) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                    const bool in = dl < WID && pos0 + dl < p.D;
+                    xv[k][j] = in ? *(const f32x4 *)(xr + dl) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                    cv[k][j] = in ? *(const f32x4 *)(cr + dl) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
                 }
             }
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
                 if (rr0 + k < nrows) {
-                    const float sr = EUCLID ? srs[rr0 + k] : 0.0f;
+                    const float sr = srs[rr0 + k], f = stg_f[rr0 + k];
                     float *gr = gxh + (row0 + rr0 + k) * p.gx_rs + pos0;
 #pragma unroll
                     for (int j = 0; j < NV; ++j) {
                         const int dl = 4 * (lane + 64 * j);
                         if (dl < WID && pos0 + dl < p.D) {
                             const f32x4 gv = *(const f32x4 *)(stg + (rr0 + k) * GS + dl);
+                            const f32x4 x4 = xv[k][j], c4 = cv[k][j];
                             f32x4 o;
-                            o.x = EUCLID ? fmaf(xv[k][j].x, sr, 0.5f * gv.x) : gv.x;
-                            o.y = EUCLID ? fmaf(xv[k][j].y, sr, 0.5f * gv.y) : gv.y;
-                            o.z = EUCLID ? fmaf(xv[k][j].z, sr, 0.5f * gv.z) : gv.z;
-                            o.w = EUCLID ? fmaf(xv[k][j].w, sr, 0.5f * gv.w) : gv.w;
+                            if (EUCLID) {
+                                o.x = fmaf(f, c4.x - x4.x, fmaf(x4.x, sr, 0.5f * gv.x));
+                                o.y = fmaf(f, c4.y - x4.y, fmaf(x4.y, sr, 0.5f * gv.y));
+                                o.z = fmaf(f, c4.z - x4.z, fmaf(x4.z, sr, 0.5f * gv.z));
+                                o.w = fmaf(f, c4.w - x4.w, fmaf(x4.w, sr, 0.5f * gv.w));
+                            } else {
+                                o.x = fmaf(f, c4.x, gv.x);
+                                o.y = fmaf(f, c4.y, gv.y);
+                                o.z = fmaf(f, c4.z, gv.z);
+                                o.w = fmaf(f, c4.w, gv.w);
+                            }
                             *(f32x4 *)(gr + dl) = o;
                         }
                     }
@@ -1241,13 +1300,15 @@ __global__ void __launch_bounds__(256, (DP <= 128 ? 2 : 1)) vq_ce_backward(const
         }
     } else {
         for (int rr = 0; rr < nrows; ++rr) {
-            const float sr = EUCLID ? srs[rr] : 0.0f;
+            const float sr = srs[rr], f = stg_f[rr];
+            const int t = stg_t[rr];
             const float *xr = xh + (row0 + rr) * p.x_rs;
+            const float *cr = cbh + (long long)(t < 0 ? 0 : t) * p.D;
             float *gr = gxh + (row0 + rr) * p.gx_rs;
             for (int dl = lane; dl < WID && pos0 + dl < p.D; dl += 64) {
                 const int d = pos0 + dl;
                 const float gv = stg[rr * GS + dl];
-                gr[d] = EUCLID ? fmaf(xr[d], sr, 0.5f * gv) : gv;
+                gr[d] = EUCLID ? fmaf(f, cr[d] - xr[d], fmaf(xr[d], sr, 0.5f * gv)) : fmaf(f, cr[d], gv);
             }
         }
     }
@@ -1610,7 +1671,7 @@ int launch_aux(int DP, const AuxParams &p, int H, int metric, int mode, hipStrea
 template <int DP, int METRIC>
 int launch_ce_bwd_t(const CeBwdParams &p, int H, hipStream_t s) {
     using G = Geo<DP, 4>;
-    const size_t stage_floats = (size_t)4 * (32 * CeGeo<DP>::GS + 32);
+    const size_t stage_floats = (size_t)4 * (32 * CeGeo<DP>::GS + 96);
     const size_t lds = 4 * ((size_t)G::MAIN_FLOATS > stage_floats ? (size_t)G::MAIN_FLOATS : stage_floats);
     auto kern = vq_ce_backward<DP, METRIC>;
     static thread_local bool attr_done = false;
@@ -2001,12 +2062,13 @@ int vq_softmax_stats_f32(const vq_args *a, float scale, const int64_t *target, i
     return launch_aux(DP, p, a->H, a->metric, kAuxStats, (hipStream_t)stream);
 }
 
-int vq_ce_backward_f32(const vq_args *a, const float *lse, const int64_t *target, int64_t tgt_rs, int64_t tgt_hs,
-                       const float *coef, float *grad_x, int64_t gx_rs, int64_t gx_hs, void *stream) {
+int vq_ce_backward_f32(const vq_args *a, const float *lse, const float *target_logit, const int64_t *target, int64_t tgt_rs,
+                       int64_t tgt_hs, const float *coef, float *grad_x, int64_t gx_rs, int64_t gx_hs, void *stream) {
     int rc = check_common(a);
     if (rc) return rc;
     if (a->M == 0) return 0;
-    if (!lse || !target || !coef || !grad_x) return fail(VQ_E_BADARG, "vq_ce_backward: null argument");
+    if (!lse || !target_logit || !target || !coef || !grad_x || !a->cb)
+        return fail(VQ_E_BADARG, "vq_ce_backward: null argument (lse / target_logit / target / coef / grad_x / cb)");
     const int DP = padded_dim(a->D);
     if (DP == 0) return fail(VQ_E_UNSUPPORTED, "vq_ce_backward: D > 512 (use vq_similarities_f32 row chunks)");
     AuxParams ap;
@@ -2020,6 +2082,8 @@ int vq_ce_backward_f32(const vq_args *a, const float *lse, const int64_t *target
     p.lse = lse;
     p.target = (const long long *)target; p.tgt_rs = tgt_rs; p.tgt_hs = tgt_hs;
     p.coef = coef;
+    p.cb = a->cb; p.cb_hs = a->cb_hs;
+    p.tgt_logit = target_logit;
     p.gx = grad_x; p.gx_rs = gx_rs; p.gx_hs = gx_hs;
     hipStream_t s = (hipStream_t)stream;
     switch (DP) {

@@ -148,19 +148,19 @@ class _CrossEntropyFn(torch.autograd.Function):
         lse, tl = search.get_backend().softmax_stats(x.detach(), codes.detach(), metric=metric, scale=1.0, target=target)
         valid = target >= 0
         count = valid.sum()
-        ctx.save_for_backward(x, codes, target, count, lse)
+        ctx.save_for_backward(x, codes, target, count, lse, tl)
         ctx.metric = metric
         return ((lse - tl) * valid).sum() / count
 
     @staticmethod
     def backward(ctx, g):
-        x, codes, target, count, lse = ctx.saved_tensors
+        x, codes, target, count, lse, tl = ctx.saved_tensors
         metric, live = ctx.metric, ctx.live_codes
         fused = getattr(search.get_backend(), "cross_entropy_backward", None)
         if fused is not None and live is None and not ctx.needs_input_grad[1]:
             # one fused sweep (S = x c^T, softmax weights, second contraction with the codebook) -- nothing of [M, K]
             coef = (g / count).reshape(1).to(torch.float32)
-            gx = fused(x.detach(), codes.detach(), lse, target, coef, metric=metric)
+            gx = fused(x.detach(), codes.detach(), lse, tl, target, coef, metric=metric)
             if gx is not None:
                 return gx, None, None, None, None
 

@@ -116,7 +116,7 @@ def load():
         lib.vq_similarities_f32.restype = ctypes.c_int
         lib.vq_softmax_stats_f32.argtypes = [ap, ctypes.c_float, _vp, _i64, _i64, _vp, _vp, _vp]
         lib.vq_softmax_stats_f32.restype = ctypes.c_int
-        lib.vq_ce_backward_f32.argtypes = [ap, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]
+        lib.vq_ce_backward_f32.argtypes = [ap, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]
         lib.vq_ce_backward_f32.restype = ctypes.c_int
         lib.vq_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         lib.vq_device_info.restype = ctypes.c_int
@@ -406,20 +406,22 @@ def softmax_stats(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, sc
 CE_BACKWARD_MAX_DIM = 512
 
 
-def ce_backward(x: torch.Tensor, cb: torch.Tensor, lse: torch.Tensor, target: torch.Tensor, coef: torch.Tensor, *,
-                metric: int = EUCLID, packed: torch.Tensor | None = None) -> torch.Tensor:
+def ce_backward(x: torch.Tensor, cb: torch.Tensor, lse: torch.Tensor, target_logit: torch.Tensor, target: torch.Tensor,
+                coef: torch.Tensor, *, metric: int = EUCLID, packed: torch.Tensor | None = None) -> torch.Tensor:
     """Fused backward of the cross entropy over the codebook: grad_x [H, M, D] = coef * d/dx (lse - logit[target]) for
-    rows with target >= 0 (0 otherwise).  lse [H, M] from softmax_stats (scale 1), coef: 1-element fp32 device tensor."""
+    rows with target >= 0 (0 otherwise).  lse, target_logit [H, M] from softmax_stats (scale 1), coef: 1-element fp32
+    device tensor."""
     a, packed = _aux_args(x, cb, metric, packed, 0)
     H, M, D = x.shape
-    _require_gpu(lse, target, coef)
+    _require_gpu(lse, target_logit, target, coef)
     assert D <= CE_BACKWARD_MAX_DIM
     assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (H, M)
+    assert target_logit.dtype == torch.float32 and target_logit.is_contiguous() and tuple(target_logit.shape) == (H, M)
     assert target.dtype == torch.int64 and tuple(target.shape) == (H, M)
     assert coef.dtype == torch.float32 and coef.numel() == 1
     gx = torch.empty((H, M, D), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(load().vq_ce_backward_f32(ctypes.byref(a), lse.data_ptr(), target.data_ptr(), int(target.stride(1)),
+        _check(load().vq_ce_backward_f32(ctypes.byref(a), lse.data_ptr(), target_logit.data_ptr(), target.data_ptr(), int(target.stride(1)),
                                          int(target.stride(0)), coef.data_ptr(), gx.data_ptr(), D, M * D,
                                          _stream_ptr(x.device)), "vq_ce_backward_f32")
     return gx

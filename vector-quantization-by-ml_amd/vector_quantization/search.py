@@ -38,11 +38,11 @@ class _NativeBackend:
 
 
     @staticmethod
-    def cross_entropy_backward(x, cb, lse, target, coef, *, metric):
+    def cross_entropy_backward(x, cb, lse, target_logit, target, coef, *, metric):
         """Fused d/dx of the cross entropy (vq_ce_backward_f32); None when the shape is outside the kernel's range."""
         if x.shape[-1] > native.CE_BACKWARD_MAX_DIM:
             return None
-        return native.ce_backward(x, cb.contiguous(), lse, target, coef, metric=metric)
+        return native.ce_backward(x, cb.contiguous(), lse, target_logit, target, coef, metric=metric)
 
 
 _backend = _NativeBackend
