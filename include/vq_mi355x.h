@@ -99,6 +99,14 @@ int64_t vq_workspace_bytes(int H, int64_t M, int Q);
  */
 int vq_quantize_f32(const vq_args *a, void *stream);
 
+/*
+ * vq_quantize_f32 for Q == 1 that ALSO emits lse[h*M + m] = log sum_k exp(similarity[h, m, k]) from the same sweep
+ * (online softmax in the search epilogue).  With a->best (the winner's distance / similarity) this is everything the
+ * cross-entropy commitment loss needs -- vector_quantize_pytorch.py:338-346 -- so that loss costs no second sweep:
+ * logit[argmax] = -best (Euclid) / best (dot).  D <= 512, fused path only (no VQ_F_FORCE_* flags).
+ */
+int vq_quantize_lse_f32(const vq_args *a, float *lse, void *stream);
+
 /* Thin named wrappers: Q must be 1 for vq_nearest_f32. */
 int vq_nearest_f32(const vq_args *a, void *stream);
 int vq_residual_f32(const vq_args *a, void *stream);

@@ -22,7 +22,16 @@ class OracleBackend:
     name = "cpu-oracle (tests only)"
 
     @staticmethod
-    def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None):
+    def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None, want_lse=False):
+        res = OracleBackend._quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, share=share,
+                                      want_best=want_best or want_lse, out=out, idx=idx)
+        if not want_lse:
+            return res
+        lse, _ = OracleBackend.softmax_stats(x, cb[:, 0], metric=metric, scale=1.0)
+        return (*res, lse)
+
+    @staticmethod
+    def _quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None):
         H, M, D = x.shape
         Q = idx.shape[-1] if (share and idx is not None) else cb.shape[1]
         xn = np.ascontiguousarray(x.detach().cpu().numpy(), dtype=np.float32)

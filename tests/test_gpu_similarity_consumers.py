@@ -182,3 +182,25 @@ def test_fused_cross_entropy_backward_strided_heads():
     want = _ce_grad_reference(x4.permute(1, 0, 2).contiguous(), cb, target.permute(1, 0).contiguous(), 0, 1.0 / rows)
     torch.cuda.synchronize()
     np.testing.assert_allclose(got.cpu().double().numpy(), want.numpy(), atol=2e-5 * float(want.abs().max()), rtol=2e-4)
+
+
+@pytest.mark.parametrize("H,M,K,D", [s for s in SHAPES if s[3] <= 512] + [(1, 8192, 256, 64), (8, 256, 8192, 64)])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_search_with_fused_log_sum_exp(oracle, H, M, K, D, metric):
+    """vq_quantize_lse_f32: same idx / best / out bits as vq_quantize_f32, plus the row's log-sum-exp (float64 check)."""
+    native = _native()
+    x, cb = make_x((H, M, D), "S"), make_codebook(H, K, D, "S")
+    if metric == 1:
+        x = x * 0.25
+    xs, cbs = x.cuda(), cb.cuda()[:, None].contiguous()
+    plain = native.quantize(xs, cbs, metric=metric, ste=True, want_sq_err=True)
+    fused = native.quantize(xs, cbs, metric=metric, ste=True, want_sq_err=True, want_lse=True)
+    torch.cuda.synchronize()
+    for key in ("idx", "best", "out"):
+        assert torch.equal(plain[key], fused[key]), key
+    # the plain call may take the split-K path (few rows): same terms, different summation order
+    torch.testing.assert_close(plain["sq_err"], fused["sq_err"], rtol=1e-6, atol=0)
+    sims = _oracle_sims(oracle, x, cb, metric).astype(np.float64)
+    mx = sims.max(-1, keepdims=True)
+    lse = (mx + np.log(np.exp(sims - mx).sum(-1, keepdims=True)))[..., 0]
+    np.testing.assert_allclose(fused["lse"].cpu().numpy(), lse, rtol=2e-6, atol=2e-5)

@@ -80,13 +80,13 @@ const DevInfo &dev_info() {
     return info;
 }
 
-template <int DP, int WAVES, int METRIC, bool MULTI>
+template <int DP, int WAVES, int METRIC, bool MULTI, bool LSE = false>
 int launch_search_t(const SearchParams &p, int H, int splits, hipStream_t s) {
     using G = Geo<DP, WAVES>;
     const size_t lds = (size_t)G::MAIN_FLOATS * 4 + (size_t)WAVES * p.Q * 32 * 4 +
                        ((MULTI && p.loss_part) ? (size_t)WAVES * p.Q * 64 * 4 : 0);
     if (lds > 160 * 1024) return fail(VQ_E_UNSUPPORTED, "vq_search: LDS budget exceeded (too many residual stages)");
-    auto kern = vq_search_mfma<DP, WAVES, METRIC, MULTI>;
+    auto kern = vq_search_mfma<DP, WAVES, METRIC, MULTI, LSE>;
     static thread_local bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -106,6 +106,10 @@ int launch_search_m(const SearchParams &p, int H, int splits, int metric, hipStr
     if (p.Q > 1) {
         if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, true>(p, H, splits, s);
         return launch_search_t<DP, WAVES, VQ_METRIC_DOT, true>(p, H, splits, s);
+    }
+    if (p.lse) {  // search + log-sum-exp in one sweep (cross-entropy commitment loss)
+        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, false, true>(p, H, splits, s);
+        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, false, true>(p, H, splits, s);
     }
     if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, false>(p, H, splits, s);
     return launch_search_t<DP, WAVES, VQ_METRIC_DOT, false>(p, H, splits, s);
@@ -390,10 +394,12 @@ int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream) {
     return 0;
 }
 
-int vq_quantize_f32(const vq_args *a, void *stream) {
+static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     int rc = check_common(a);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (lse && (a->Q != 1 || padded_dim(a->D) == 0 || (a->flags & (VQ_F_FORCE_SIMPLE | VQ_F_FORCE_SPLIT))))
+        return fail(VQ_E_UNSUPPORTED, "vq_quantize_lse: needs Q == 1, D <= 512 and the fused MFMA path");
     if (a->M > 0 && !a->idx) return fail(VQ_E_BADARG, "vq_quantize: idx is null");
     if (a->M > 0 && !a->cb) return fail(VQ_E_BADARG, "vq_quantize: natural codebook is null");
     if (a->M == 0) {
@@ -426,6 +432,7 @@ int vq_quantize_f32(const vq_args *a, void *stream) {
         // few workgroups and a long sweep: splitting K over workgroups fills the chip (Q == 1 only)
         if (a->Q == 1 && wgs * 2 <= cus && ntiles * sub_tiles(DP) >= 8 && ntiles >= 2) fused = false;
         if ((a->flags & VQ_F_FORCE_SPLIT) && a->Q == 1) fused = false;
+        if (lse) fused = true;  // the log-sum-exp needs every code of a row in one workgroup
     }
 
     if (fused) {
@@ -436,6 +443,7 @@ int vq_quantize_f32(const vq_args *a, void *stream) {
         fill_search_params(p, a);
         p.mode = kModeFused;
         p.loss_part = a->sq_err ? loss_part : nullptr;
+        p.lse = lse;
         rc = launch_search(DP, waves, p, a->H, 1, a->metric, s);
         if (rc) return rc;
         if (a->sq_err) {
@@ -462,6 +470,13 @@ int vq_quantize_f32(const vq_args *a, void *stream) {
         if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
     }
     return 0;
+}
+
+int vq_quantize_f32(const vq_args *a, void *stream) { return quantize_impl(a, stream, nullptr); }
+
+int vq_quantize_lse_f32(const vq_args *a, float *lse, void *stream) {
+    if (!lse && a && a->M > 0) return fail(VQ_E_BADARG, "vq_quantize_lse: lse is null");
+    return quantize_impl(a, stream, lse);
 }
 
 int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs, int64_t idx_hs,

@@ -141,15 +141,21 @@ class Codebook(nn.Module):
 
     # ------------------------------------------------------------------ the hot path
     def quantize_flat(self, flat: torch.Tensor, *, ste: bool = False, want_sq_err: bool = False,
-                      codebook_grad_from_err: bool = False, out=None, idx=None):
-        """flat [h, M, D] (strided rows fine) -> (out [h, M, D], idx [h, M] int64, sq_err [1] float64 | None)."""
+                      codebook_grad_from_err: bool = False, out=None, idx=None, want_lse: bool = False):
+        """flat [h, M, D] (strided rows fine) -> (out [h, M, D], idx [h, M] int64, sq_err [1] float64 | None).
+        ``want_lse``: a fourth element (lse [h, M], target_logit [h, M]) -- log-sum-exp of the row's similarities and the
+        similarity of the chosen code, from the same sweep -- or None when the sampling is stochastic."""
         if self._stochastic_requested():
-            return self._quantize_stochastic(flat, ste=ste, want_sq_err=want_sq_err,
-                                             codebook_grad_from_err=codebook_grad_from_err, idx=idx)
+            res = self._quantize_stochastic(flat, ste=ste, want_sq_err=want_sq_err,
+                                            codebook_grad_from_err=codebook_grad_from_err, idx=idx)
+            return (*res, None) if want_lse else res
         codes = self.current_codes()
-        out, idx, sq_err = search.quantize_rows(flat, codes[:, None], metric=self.metric, ste=ste,
-                                                want_sq_err=want_sq_err,
-                                                codebook_grad_from_err=codebook_grad_from_err, out=out, idx=idx)
+        res = search.quantize_rows(flat, codes[:, None], metric=self.metric, ste=ste, want_sq_err=want_sq_err,
+                                   codebook_grad_from_err=codebook_grad_from_err, out=out, idx=idx, want_lse=want_lse)
+        out, idx, sq_err = res[:3]
+        if want_lse:
+            best = res[3]["best"][..., 0]
+            return out, idx[..., 0], sq_err, (res[3]["lse"], best if self.use_cosine_sim else -best)
         return out, idx[..., 0], sq_err
 
     def _quantize_stochastic(self, flat, *, ste, want_sq_err, codebook_grad_from_err, idx=None):

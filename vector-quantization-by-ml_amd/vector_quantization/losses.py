@@ -143,9 +143,11 @@ class _CrossEntropyFn(torch.autograd.Function):
     Forward: one native sweep (online softmax).  Backward: bounded chunks of the similarity matrix."""
 
     @staticmethod
-    def forward(ctx, x, codes, target, metric, live_codes=None):
+    def forward(ctx, x, codes, target, metric, live_codes=None, lse=None, tl=None):
         ctx.live_codes = live_codes
-        lse, tl = search.get_backend().softmax_stats(x.detach(), codes.detach(), metric=metric, scale=1.0, target=target)
+        if lse is None:  # otherwise the search already produced them (vq_quantize_lse_f32): no second sweep
+            lse, tl = search.get_backend().softmax_stats(x.detach(), codes.detach(), metric=metric, scale=1.0,
+                                                         target=target)
         valid = target >= 0
         count = valid.sum()
         ctx.save_for_backward(x, codes, target, count, lse, tl)
@@ -162,7 +164,7 @@ class _CrossEntropyFn(torch.autograd.Function):
             coef = (g / count).reshape(1).to(torch.float32)
             gx = fused(x.detach(), codes.detach(), lse, tl, target, coef, metric=metric)
             if gx is not None:
-                return gx, None, None, None, None
+                return gx, None, None, None, None, None, None
 
         def chunk_value(xc, cc, rows):
             sims = similarity_matrix(xc, cc, metric, live)
@@ -171,14 +173,18 @@ class _CrossEntropyFn(torch.autograd.Function):
 
         chunks = _row_slices(x.shape[1], _rows_per_chunk(x.shape[0], codes.shape[1]))
         gx, gc = _chunk_grads(chunk_value, x, codes, chunks, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        return gx, gc, None, None, None
+        return gx, gc, None, None, None, None, None
 
 
 def cross_entropy_to_codes(x: torch.Tensor, codes: torch.Tensor, target: torch.Tensor, metric: int,
-                           live_codes=None) -> torch.Tensor:
+                           live_codes=None, stats=None) -> torch.Tensor:
     """x [H, M, D] (strided rows fine), codes [H, K, D], target [H, M] int64 with -1 = ignore -> scalar.
-    ``live_codes``: see similarity_matrix()."""
-    return _CrossEntropyFn.apply(x.float(), codes, target, metric, live_codes)
+    ``live_codes``: see similarity_matrix().  ``stats`` = (lse [H, M], target_logit [H, M]) when the search sweep already
+    produced them for exactly this target (cross-entropy commitment loss: target = the chosen code)."""
+    lse, tl = stats if stats is not None else (None, None)
+    if lse is not None:
+        lse, tl = lse.contiguous(), tl.contiguous()
+    return _CrossEntropyFn.apply(x.float(), codes, target, metric, live_codes, lse, tl)
 
 
 # ------------------------------------------------------------------------------------------------ diversity

@@ -96,6 +96,8 @@ def load():
         lib.vq_workspace_bytes.restype = _i64
         lib.vq_pack_codebooks_f32.argtypes = [_vp, ctypes.c_int, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]
         lib.vq_pack_codebooks_f32.restype = ctypes.c_int
+        lib.vq_quantize_lse_f32.argtypes = [ap, _vp, _vp]
+        lib.vq_quantize_lse_f32.restype = ctypes.c_int
         for name in ("vq_quantize_f32", "vq_nearest_f32", "vq_residual_f32"):
             fn = getattr(lib, name)
             fn.argtypes = [ap, _vp]
@@ -128,7 +130,7 @@ EXPORTED_SYMBOLS = (
     "vq_packed_floats", "vq_pack_codebooks_f32", "vq_workspace_bytes", "vq_quantize_f32", "vq_nearest_f32",
     "vq_residual_f32", "vq_keys_init", "vq_search_keys_f32", "vq_finalize_keys_f32", "vq_last_error",
     "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32", "vq_similarities_f32", "vq_softmax_stats_f32",
-    "vq_ce_backward_f32",
+    "vq_ce_backward_f32", "vq_quantize_lse_f32",
 )
 
 
@@ -191,14 +193,16 @@ def _row_strides(t: torch.Tensor):
 def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bool = False, want_out: bool = True,
              want_sq_err: bool = False, want_best: bool = True, packed: torch.Tensor | None = None,
              stages_share_codebook: bool = False, flags: int = 0, out: torch.Tensor | None = None,
-             idx: torch.Tensor | None = None):
+             idx: torch.Tensor | None = None, want_lse: bool = False):
     """The hot path through the C ABI.
 
     x   [H, M, D] fp32 (rows may be strided, last dim contiguous)
     cb  [H, Q, K, D] fp32 contiguous natural codebooks ([H, 1, K, D] with stages_share_codebook; Q stages
         are then given by ``idx.shape[-1]`` or default to 1)
     out [H, M, D] optional destination VIEW (any row / head strides), idx [H, M, Q] optional int64 VIEW
-    returns dict(out [H, M, D] | None, idx [H, M, Q] int64, best [H, M, Q] | None, sq_err [Q] float64 | None)
+    want_lse (Q == 1): also the per-row log-sum-exp of the similarities over the codebook, from the same sweep
+    returns dict(out [H, M, D] | None, idx [H, M, Q] int64, best [H, M, Q] | None, sq_err [Q] float64 | None,
+                 lse [H, M] | None)
     """
     _require_gpu(x, cb)
     assert x.dtype == torch.float32 and cb.dtype == torch.float32
@@ -247,11 +251,17 @@ def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bo
         if _event_sink is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(dev))
-        _check(load().vq_quantize_f32(ctypes.byref(a), _stream_ptr(dev)), "vq_quantize_f32")
+        if want_lse:
+            assert Q == 1
+            lse = torch.empty((H, M), dtype=torch.float32, device=dev)
+            _check(load().vq_quantize_lse_f32(ctypes.byref(a), lse.data_ptr(), _stream_ptr(dev)), "vq_quantize_lse_f32")
+        else:
+            lse = None
+            _check(load().vq_quantize_f32(ctypes.byref(a), _stream_ptr(dev)), "vq_quantize_f32")
         if _event_sink is not None:
             e1.record(torch.cuda.current_stream(dev))
             _event_sink.append((e0, e1))
-    return dict(out=out, idx=idx, best=best, sq_err=sq_err)
+    return dict(out=out, idx=idx, best=best, sq_err=sq_err, lse=lse)
 
 
 def keys_init(keys: torch.Tensor):

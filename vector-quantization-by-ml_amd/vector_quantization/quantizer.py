@@ -211,14 +211,21 @@ class VectorQuantize(nn.Module):
             self.in_place_codebook_optimizer.zero_grad()
             if will_update:  # the reference's first Codebook.forward already ran its EMA step
                 cb.ema_step(flat.detach(), first_idx, flat_mask)
+        # cross-entropy commitment: the search sweep also emits the row's log-sum-exp (no second sweep for the loss)
+        ce_from_search = training and want_loss and use_ce
+        ce_stats = None
         if mask is None:
             # the one native launch: search + gather + straight-through + squared error
-            out, idx, sq_err = cb.quantize_flat(flat, ste=training, want_sq_err=want_sq_err,
-                                                codebook_grad_from_err=cb_grad_from_err, out=out_view, idx=idx_view)
+            out, idx, sq_err, *rest = cb.quantize_flat(flat, ste=training, want_sq_err=want_sq_err,
+                                                       codebook_grad_from_err=cb_grad_from_err, out=out_view,
+                                                       idx=idx_view, want_lse=ce_from_search)
+            ce_stats = rest[0] if rest else None
             if want_sq_err:
                 commit_loss = (sq_err[0] / flat.numel()).to(torch.float32)
         else:
-            out, idx, _ = cb.quantize_flat(flat.detach() if not cb_grad_from_err else flat, ste=False, idx=idx_view)
+            out, idx, _, *rest = cb.quantize_flat(flat.detach() if not cb_grad_from_err else flat, ste=False, idx=idx_view,
+                                                  want_lse=ce_from_search)
+            ce_stats = rest[0] if rest else None
             if want_sq_err:
                 target = out if cb_grad_from_err else out.detach()
                 commit_loss = ((target - flat) ** 2)[flat_mask].mean()
@@ -245,7 +252,7 @@ class VectorQuantize(nn.Module):
                 target = idx_view[..., 0]
                 if flat_mask is not None:
                     target = target.masked_fill(~flat_mask, -1)
-                commit_loss = losses.cross_entropy_to_codes(flat, codes, target, cb.metric, live)
+                commit_loss = losses.cross_entropy_to_codes(flat, codes, target, cb.metric, live, stats=ce_stats)
             if training and self.has_codebook_diversity_loss and not return_loss:
                 row_id = torch.arange(flat.shape[1], device=flat.device)
                 position = (row_id % n) if (self.separate_codebook_per_head or heads == 1) else (row_id // heads) % n

@@ -21,9 +21,13 @@ class _NativeBackend:
     name = "hip-gfx950"
 
     @staticmethod
-    def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None):
-        r = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, want_best=want_best,
-                            stages_share_codebook=share, out=out, idx=idx)
+    def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None, want_lse=False):
+        """-> (out, idx, best, sq_err) and, with ``want_lse`` (single stage), a fifth element: the per-row log-sum-exp
+        of the similarities from the same sweep (vq_quantize_lse_f32)."""
+        r = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, want_best=want_best or want_lse,
+                            stages_share_codebook=share, out=out, idx=idx, want_lse=want_lse)
+        if want_lse:
+            return r["out"], r["idx"], r["best"], r["sq_err"], r["lse"]
         return r["out"], r["idx"], r["best"], r["sq_err"]
 
     @staticmethod
@@ -71,18 +75,22 @@ class _QuantizeFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out_buf, idx_buf):
-        out, idx, _best, sq_err = _backend.quantize(x.detach(), cb.detach(), metric=metric, ste=ste,
-                                                    want_sq_err=want_sq_err, share=share, out=out_buf, idx=idx_buf)
+    def forward(ctx, x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out_buf, idx_buf, want_lse=False):
+        res = _backend.quantize(x.detach(), cb.detach(), metric=metric, ste=ste, want_sq_err=want_sq_err, share=share,
+                                out=out_buf, idx=idx_buf, **({"want_lse": True} if want_lse else {}))
+        out, idx, best, sq_err = res[:4]
         ctx.save_for_backward(x, cb, idx)
         ctx.ste, ctx.share, ctx.cb_err = ste, share, codebook_grad_from_err
-        ctx.mark_non_differentiable(idx)
         if sq_err is None:
             sq_err = torch.zeros(idx.shape[-1], dtype=torch.float64, device=x.device)
+        if want_lse:
+            ctx.mark_non_differentiable(idx, best, res[4])
+            return out, idx, sq_err, best, res[4]
+        ctx.mark_non_differentiable(idx)
         return out, idx, sq_err
 
     @staticmethod
-    def backward(ctx, g_out, _g_idx, g_err):
+    def backward(ctx, g_out, _g_idx, g_err, *_unused):
         x, cb, idx = ctx.saved_tensors
         H, M, D = x.shape
         Q = idx.shape[-1]
@@ -112,16 +120,18 @@ class _QuantizeFn(torch.autograd.Function):
                     gcb[:, 0 if ctx.share else q].index_put_((harange.expand_as(i), i), g_out, accumulate=True)
                 quant = r + (c - r) if ctx.ste else c
                 r = r - quant
-        return gx, gcb, None, None, None, None, None, None, None
+        return gx, gcb, None, None, None, None, None, None, None, None
 
 
 def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bool = False,
                   want_sq_err: bool = False, share: bool = False, codebook_grad_from_err: bool = False,
-                  out: Optional[torch.Tensor] = None, idx: Optional[torch.Tensor] = None):
+                  out: Optional[torch.Tensor] = None, idx: Optional[torch.Tensor] = None, want_lse: bool = False):
     """x [H, M, D] (strided rows allowed), cb [H, Q, K, D] contiguous ([H, 1, K, D] when ``share``; the number
     of stages is then ``idx.shape[-1]``).  ``out`` / ``idx`` may be pre-allocated (strided) destination views.
 
-    Returns (out [H, M, D], idx [H, M, Q] int64, sq_err [Q] float64 or None).
+    Returns (out [H, M, D], idx [H, M, Q] int64, sq_err [Q] float64 or None); with ``want_lse`` (single stage) a fourth
+    element: dict(best [H, M, 1], lse [H, M]) -- the winner's distance / similarity and the log-sum-exp of the row's
+    similarities, both from the same sweep (what the cross-entropy commitment loss needs).
     """
     if x.dtype != torch.float32:
         x = x.float()
@@ -129,8 +139,15 @@ def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, st
         cb = cb.contiguous()
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or cb.requires_grad)
     if needs_grad:
-        out, idx, sq_err = _QuantizeFn.apply(x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out, idx)
+        res = _QuantizeFn.apply(x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out, idx, want_lse)
+        out, idx, sq_err = res[:3]
+        if want_lse:
+            return out, idx, (sq_err if want_sq_err else None), dict(best=res[3], lse=res[4])
         return out, idx, (sq_err if want_sq_err else None)
+    if want_lse:
+        out, idx, best, sq_err, lse = _backend.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err,
+                                                        share=share, out=out, idx=idx, want_lse=True)
+        return out, idx, sq_err, dict(best=best, lse=lse)
     out, idx, _best, sq_err = _backend.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, share=share,
                                                 out=out, idx=idx)
     return out, idx, sq_err
