@@ -213,6 +213,11 @@ def test_random_projection_quantizer(device):
     assert agree > 0.99, agree  # fp32 summation order may flip exact near-ties only
     picked = torch.gather(sims, -1, idx[..., None])[..., 0]
     torch.testing.assert_close(picked, sims.max(-1).values, rtol=0, atol=1e-5)
+    # BEST-RQ training target: cross entropy of the (cosine) similarities against given labels
+    labels = torch.randint(0, 40, (2, 30, 3), device=device)
+    ce = mod(x, indices=labels)
+    want = torch.nn.functional.cross_entropy(sims.permute(0, 3, 1, 2), labels)
+    torch.testing.assert_close(ce, want, rtol=1e-5, atol=1e-5)
 
 
 # ---------------------------------------------------------------------------------------------- stochastic sampling

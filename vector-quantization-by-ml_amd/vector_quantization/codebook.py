@@ -226,9 +226,7 @@ class Codebook(nn.Module):
         quantize = out.reshape(h, *lead, d)
         embed_ind = idx.reshape(h, *lead)
         if squeeze_head:
-            quantize, embed_ind = quantize[0], embed_ind[0]
-            if sims is not None:
-                sims = sims  # keeps the head dim, like the reference (codebooks.py:433)
+            quantize, embed_ind = quantize[0], embed_ind[0]  # `sims` keeps the head dim, like the reference (codebooks.py:433)
         return quantize, embed_ind, sims
 
     # ------------------------------------------------------------------ training-state bookkeeping

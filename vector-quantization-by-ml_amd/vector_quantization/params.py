@@ -29,7 +29,8 @@ class KmeansParameters:
 
 @dataclass
 class GumbelParams:
-    """Sampling options of the code selection; only the deterministic argmax branch is native."""
+    """Sampling options of the code selection: deterministic argmax (native, bit-exact) or stochastic Gumbel-max sampling
+    (native similarities + device RNG); the straight-through / reinmax relaxations are not provided."""
 
     temperature: float = 1.0
     stochastic: bool = False

@@ -30,11 +30,14 @@ class RandomProjectionQuantizer(nn.Module):
                                  heads=num_codebooks, separate_codebook_per_head=True, **kwargs)
 
     def forward(self, x, indices=None):
-        if indices is not None:
-            raise NotImplementedError("cross-entropy to given indices needs the similarity matrix (SURVEY 8f rank 3)")
+        """-> code indices [b, n, num_codebooks] (or [b, n]); with ``indices`` the cross entropy of the similarities
+        against them (random_projection_quantizer.py:40-60)."""
         x = self.norm(x)
         x = torch.einsum("bnd,hde->bnhe", x, self.rand_projs)
         x = x.reshape(x.shape[0], x.shape[1], -1)
         self.vq.eval()
+        if indices is not None:
+            _, ce_loss = self.vq(x, indices=indices)
+            return ce_loss
         _, found, _ = self.vq(x)
         return found
