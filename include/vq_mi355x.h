@@ -134,7 +134,8 @@ int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream);
  *   Replaces embed_onehot.sum(1) and einsum("h n d, h n c -> h c d") -- codebooks.py:405-415 -- without the one-hot.
  * vq_ema_update_f32: cluster_size.lerp_(counts, 1-decay); embed_avg.lerp_(sums, 1-decay); embeddings =
  *   [l2norm](embed_avg / laplace_smoothing(cluster_size) * total) -- codebooks.py:411,417-425.  total_scratch: H floats.
- * Float atomics: the sums are exact up to fp32 summation order (run-to-run differences at the 1e-7 relative level).
+ * The sums are exact up to fp32 summation order (float atomics / per-wave partial sums: run-to-run differences at the
+ * 1e-7 relative level).
  */
 int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs, int64_t idx_hs,
                           const uint8_t *mask, int H, int64_t M, int K, int D, float *counts, float *sums, void *stream);

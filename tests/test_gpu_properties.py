@@ -244,3 +244,34 @@ def test_integration_md_stub_runs_as_written(oracle):
     ref = oracle.vq_forward(x.numpy(), cb.numpy(), oracle.EUCLID)
     np.testing.assert_array_equal(idx.cpu().numpy(), ref["idx"])
     np.testing.assert_array_equal(out.cpu().numpy(), ref["out"])
+
+
+@pytest.mark.parametrize("H,M,K,D,masked", [
+    (1, 262144, 1024, 256, False),  # cfg2: owner-computes kernel (a wave owns 8 codes)
+    (1, 40000, 300, 100, True),     # owner kernel: 20 codes per wave, mask
+    (3, 30000, 200, 64, False),     # owner kernel: heads (strided rows), 32 codes per wave
+    (2, 20000, 100, 24, True),      # owner kernel: D smaller than a wave pass, unaligned row stride
+    (1, 50000, 40, 600, False),     # owner kernel: D > 256 (two passes per row), 3 codes per wave
+    (1, 65536, 1024, 256, False),   # too few rows per owner: memory-side atomics
+    (1, 6000, 8192, 64, False),     # memory-side atomics
+    (1, 1000, 256, 64, False),      # memory-side atomics
+])
+def test_ema_accumulate_paths_match_index_add(H, M, K, D, masked):
+    """vq_ema_accumulate_f32 (owner-computes kernel and memory-side-atomic kernel) == index_add_ in float64."""
+    from vector_quantization import native
+
+    g = torch.Generator().manual_seed(H * 1000 + K)
+    x4 = torch.randn((M, H, D), generator=g)
+    x = x4.cuda().permute(1, 0, 2)                      # [H, M, D] with strided rows, like the head-split module view
+    idx = torch.randint(0, K, (H, M), generator=g).cuda()
+    mask = (torch.rand((H, M), generator=g) > 0.3).cuda() if masked else None
+    counts, sums = native.ema_accumulate(x, idx, K, mask)
+    torch.cuda.synchronize()
+    w = mask.double() if masked else torch.ones((H, M), dtype=torch.float64, device="cuda")
+    want_c = torch.zeros((H, K), dtype=torch.float64, device="cuda")
+    want_s = torch.zeros((H, K, D), dtype=torch.float64, device="cuda")
+    for h in range(H):
+        want_c[h].index_add_(0, idx[h], w[h])
+        want_s[h].index_add_(0, idx[h], x[h].double() * w[h][:, None])
+    assert torch.equal(counts.double(), want_c)
+    torch.testing.assert_close(sums.double(), want_s, rtol=1e-5, atol=1e-4)

@@ -65,5 +65,27 @@ def main():
     print(f"VectorQuantize CE commitment, forward only                                 {t:8.2f} ms")
 
 
+def train_steps():
+    """Training-mode module forwards at cfg2 (no autograd): search + straight-through + loss (+ EMA codebook update)."""
+    dev = "cuda:0"
+    D, K = 256, 1024
+    xs = torch.randn(256, 1024, D, device=dev)
+    for name, kw, fkw in (
+        ("train, MSE commitment, codebook frozen", {}, dict(freeze_codebook=True)),
+        ("train, MSE commitment, EMA codebook update", {}, {}),
+        ("train, cross-entropy commitment, EMA codebook update", dict(commitment_use_cross_entropy_loss=True), {}),
+    ):
+        mod = vq.VectorQuantize(dim=D, codebook_params=CodebookParams(dim=D, codebook_size=K, threshold_ema_dead_code=0),
+                                **kw).to(dev).train()
+
+        def fwd():
+            with torch.no_grad():
+                mod(xs, **fkw)
+
+        t = timed(fwd, n=10, warm=3)
+        print(f"VectorQuantize forward, {name:55s} {t:8.3f} ms  {xs.shape[0] * xs.shape[1] / t / 1e3:8.1f} M rows/s")
+
+
 if __name__ == "__main__":
     main()
+    train_steps()

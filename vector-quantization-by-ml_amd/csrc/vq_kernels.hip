@@ -484,9 +484,44 @@ int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int6
     if (H <= 0 || M < 0 || K <= 0 || D <= 0 || !counts || !sums) return fail(VQ_E_BADARG, "vq_ema_accumulate: bad argument");
     if (M == 0) return 0;
     if (!x || !idx) return fail(VQ_E_BADARG, "vq_ema_accumulate: null input");
+    hipStream_t s = (hipStream_t)stream;
+    // Owner-computes path: a wave owns cw codes (8 KiB of partial sums) -- worth it when each owner sees many rows
+    if (D <= 2048) {
+        const int D4 = (D + 3) & ~3;
+        int cw = 2048 / D4;
+        if (cw > 64) cw = 64;
+        if (cw > K) cw = K;
+        const long long owners = (K + cw - 1) / cw;
+        if (M / owners >= 1024) {
+            const DevInfo &di = dev_info();
+            const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+            long long row_blocks = (16ll * cus) / (owners * H);  // ~16 waves per CU in total
+            if (row_blocks < 1) row_blocks = 1;
+            long long rows_per_block = (M + row_blocks - 1) / row_blocks;
+            if (rows_per_block < 2048) rows_per_block = 2048;
+            rows_per_block = (rows_per_block + 63) / 64 * 64;
+            row_blocks = (M + rows_per_block - 1) / rows_per_block;
+            const size_t per_wave = (size_t)cw * D4 + ((cw + 3) & ~3) + 64 * 2 + 64;
+            const size_t lds = per_wave * 4 * 4;
+            static thread_local bool attr_done = false;
+            if (!attr_done) {
+                hipError_t e = hipFuncSetAttribute((const void *)vq_ema_accumulate_owner_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(vq_ema_accumulate_owner_kernel,
+                               dim3((unsigned)((owners + 3) / 4), (unsigned)row_blocks, (unsigned)H), dim3(256), lds, s, x,
+                               (long long)x_rs, (long long)x_hs, (const long long *)idx, (long long)idx_rs,
+                               (long long)idx_hs, mask, (long long)M, rows_per_block, K, cw, D, counts, sums);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "vq_ema_accumulate_owner launch");
+            return 0;
+        }
+    }
     long long blocks = (M + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(vq_ema_accumulate_kernel, dim3((unsigned)blocks, (unsigned)H), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL(vq_ema_accumulate_kernel, dim3((unsigned)blocks, (unsigned)H), dim3(256), 0, s, x,
                        (long long)x_rs, (long long)x_hs, (const long long *)idx, (long long)idx_rs, (long long)idx_hs, mask,
                        (long long)M, K, D, counts, sums);
     hipError_t e = hipGetLastError();
