@@ -127,6 +127,17 @@ int vq_search_keys_f32(const vq_args *a, int64_t idx_offset, int64_t *keys, void
 int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream);
 
 /*
+ * Backward of vq_quantize_f32 with respect to x (the autograd of the quantize step, vector_quantize_pytorch.py:261-279,
+ * 361-364, and of the residual loop, residual_vq.py:212-243), one pass:
+ *   grad_x = (VQ_F_STE ? Q * grad_out : 0) + sum_q 2 * grad_sq_err[q] * (r_q - c_q[idx_q])
+ * Uses a->x, a->cb (cb_qs = 0: shared codebook), a->idx as written by the forward, H, M, D, Q, flags.  grad_out (same
+ * layout conventions as out) and grad_sq_err ([Q] doubles on the device) may each be NULL.  The codebook receives no
+ * gradient here (learnable codebooks take the PyTorch path).
+ */
+int vq_quantize_backward_f32(const vq_args *a, const float *grad_out, int64_t go_rs, int64_t go_hs, const double *grad_sq_err,
+                             float *grad_x, int64_t gx_rs, int64_t gx_hs, void *stream);
+
+/*
  * Training-state step that FOLLOWS the hot path -- exponential-moving-average codebook update.
  * vq_ema_accumulate_f32: counts[h*K + k] += 1 and sums[(h*K + k)*D + d] += x[h, m, d] for every row m assigned to
  *   code k = idx[h*idx_hs + m*idx_rs] (rows with mask[h*M + m] == 0 are skipped; mask may be NULL).  The caller

@@ -252,3 +252,63 @@ def test_multihead_mask_train_matches_manual():
     torch.testing.assert_close(loss[0], manual, rtol=1e-5, atol=1e-7)
     assert torch.equal(q[~mask], x[~mask])
     torch.testing.assert_close(q[mask], (xh + (sel - xh)).reshape(3, 10, 32)[mask], rtol=0, atol=1e-6)
+
+
+class _TorchBackwardBackend:
+    """The native backend minus the fused backward kernels: autograd then takes the PyTorch formulas in search.py /
+    losses.py -- the reference implementation the native backward passes are compared with."""
+    name = "hip-gfx950 (torch backward)"
+
+    def __init__(self):
+        from vector_quantization import search
+
+        native_backend = search._NativeBackend
+        self.quantize = native_backend.quantize
+        self.similarities = native_backend.similarities
+        self.softmax_stats = native_backend.softmax_stats
+
+
+@pytest.mark.parametrize("kind", ["vq", "vq_eval_learnable_off", "vq_heads_sep", "vq_heads_shared", "rvq", "rvq_shared", "grvq"])
+def test_native_quantize_backward_equals_torch_formulas(kind):
+    """vq_quantize_backward_f32 (one pass) vs the gather + elementwise autograd formulas, on the same modules."""
+    import vector_quantization as vq
+    from vector_quantization import search
+    from vector_quantization.codebooks import CodebookParams
+
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    if kind.startswith("vq"):
+        kw = dict(vq_heads_sep=dict(dim=64, heads=2, codebook_dim=32, separate_codebook_per_head=True),
+                  vq_heads_shared=dict(dim=64, heads=2, codebook_dim=32)).get(kind, dict(dim=64))
+        mod = vq.VectorQuantize(codebook_params=CodebookParams(dim=kw.get("codebook_dim", 64), codebook_size=128),
+                                commitment_weight=0.7, **kw).to(dev)
+        x = torch.randn(3, 50, 64, device=dev)
+    elif kind == "grvq":
+        mod = vq.GroupedResidualVQ(dim=64, groups=2, num_quantizers=3,
+                                   codebook_params=CodebookParams(dim=32, codebook_size=64)).to(dev)
+        x = torch.randn(3, 50, 64, device=dev)
+    else:
+        mod = vq.ResidualVQ(dim=48, num_quantizers=4, shared_codebook=(kind == "rvq_shared"),
+                            codebook_params=CodebookParams(dim=48, codebook_size=96)).to(dev)
+        x = torch.randn(3, 50, 48, device=dev)
+    mod.train()
+    if kind == "vq_eval_learnable_off":
+        mod.eval()
+    w = torch.randn_like(x)
+
+    def grads(backend):
+        search.set_backend(backend)
+        try:
+            xs = x.clone().requires_grad_(True)
+            out = mod(xs, freeze_codebook=True) if mod.training else mod(xs)
+            objective = (out[0] * w).sum() + out[2].sum() * 3.0
+            if not objective.requires_grad:
+                return torch.zeros_like(xs)
+            objective.backward()
+            return xs.grad if xs.grad is not None else torch.zeros_like(xs)
+        finally:
+            search.set_backend(None)
+
+    got = grads(None)
+    want = grads(_TorchBackwardBackend())
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6 * float(want.abs().max() + 1e-30))

@@ -479,6 +479,32 @@ int vq_quantize_lse_f32(const vq_args *a, float *lse, void *stream) {
     return quantize_impl(a, stream, lse);
 }
 
+int vq_quantize_backward_f32(const vq_args *a, const float *grad_out, int64_t go_rs, int64_t go_hs, const double *grad_sq_err,
+                             float *grad_x, int64_t gx_rs, int64_t gx_hs, void *stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (a->M == 0) return 0;
+    if (!a->cb || !a->idx || !grad_x) return fail(VQ_E_BADARG, "vq_quantize_backward: cb / idx / grad_x is null");
+    QuantBwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = a->x; p.x_rs = a->x_rs; p.x_hs = a->x_hs;
+    p.cb = a->cb; p.cb_hs = a->cb_hs; p.cb_qs = a->cb_qs;
+    p.idx = (const long long *)a->idx; p.idx_rs = a->idx_rs; p.idx_hs = a->idx_hs; p.idx_qs = a->idx_qs;
+    p.go = grad_out; p.go_rs = go_rs; p.go_hs = go_hs;
+    p.g_err = grad_sq_err;
+    p.gx = grad_x; p.gx_rs = gx_rs; p.gx_hs = gx_hs;
+    p.M = a->M; p.D = a->D; p.Q = a->Q; p.ste = (a->flags & VQ_F_STE) ? 1 : 0;
+    p.vec = (a->D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x) && gx_rs % 4 == 0 && gx_hs % 4 == 0 &&
+             aligned16(grad_x) && a->cb_hs % 4 == 0 && a->cb_qs % 4 == 0 && aligned16(a->cb) &&
+             (!grad_out || (go_rs % 4 == 0 && go_hs % 4 == 0 && aligned16(grad_out)))) ? 1 : 0;
+    long long blocks = (a->M + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(vq_quantize_backward_kernel, dim3((unsigned)blocks, (unsigned)a->H), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_quantize_backward launch");
+    return 0;
+}
+
 int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs, int64_t idx_hs,
                           const uint8_t *mask, int H, int64_t M, int K, int D, float *counts, float *sums, void *stream) {
     if (H <= 0 || M < 0 || K <= 0 || D <= 0 || !counts || !sums) return fail(VQ_E_BADARG, "vq_ema_accumulate: bad argument");

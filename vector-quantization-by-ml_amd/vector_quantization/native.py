@@ -120,6 +120,8 @@ def load():
         lib.vq_softmax_stats_f32.restype = ctypes.c_int
         lib.vq_ce_backward_f32.argtypes = [ap, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]
         lib.vq_ce_backward_f32.restype = ctypes.c_int
+        lib.vq_quantize_backward_f32.argtypes = [ap, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]
+        lib.vq_quantize_backward_f32.restype = ctypes.c_int
         lib.vq_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         lib.vq_device_info.restype = ctypes.c_int
         _lib = lib
@@ -131,6 +133,7 @@ EXPORTED_SYMBOLS = (
     "vq_residual_f32", "vq_keys_init", "vq_search_keys_f32", "vq_finalize_keys_f32", "vq_last_error",
     "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32", "vq_similarities_f32", "vq_softmax_stats_f32",
     "vq_ce_backward_f32", "vq_quantize_lse_f32",
+    "vq_quantize_backward_f32",
 )
 
 
@@ -434,4 +437,40 @@ def ce_backward(x: torch.Tensor, cb: torch.Tensor, lse: torch.Tensor, target_log
         _check(load().vq_ce_backward_f32(ctypes.byref(a), lse.data_ptr(), target_logit.data_ptr(), target.data_ptr(), int(target.stride(1)),
                                          int(target.stride(0)), coef.data_ptr(), gx.data_ptr(), D, M * D,
                                          _stream_ptr(x.device)), "vq_ce_backward_f32")
+    return gx
+
+
+def quantize_backward(x: torch.Tensor, cb: torch.Tensor, idx: torch.Tensor, grad_out: torch.Tensor | None,
+                      grad_sq_err: torch.Tensor | None, *, ste: bool, stages_share_codebook: bool = False) -> torch.Tensor:
+    """d/dx of the quantize step in one pass: x [H, M, D] (strided rows ok), cb [H, Q|1, K, D], idx [H, M, Q] (any
+    strides), grad_out [H, M, D] | None, grad_sq_err [Q] float64 | None  ->  grad_x [H, M, D] contiguous."""
+    _require_gpu(x, cb, idx, grad_out, grad_sq_err)
+    assert x.dtype == torch.float32 and cb.dtype == torch.float32 and cb.is_contiguous() and idx.dtype == torch.int64
+    H, M, D = x.shape
+    Hc, Qc, K, Dc = cb.shape
+    Q = idx.shape[-1]
+    assert Hc == H and Dc == D and tuple(idx.shape[:2]) == (H, M) and (Qc == Q or (stages_share_codebook and Qc == 1))
+    gx = torch.empty((H, M, D), dtype=torch.float32, device=x.device)
+    x_rs, x_hs = _row_strides(x)
+    a = VqArgs()
+    a.H, a.Q, a.M, a.K, a.D, a.metric = H, Q, M, K, D, EUCLID
+    a.flags = F_STE if ste else 0
+    a.x, a.x_rs, a.x_hs = x.data_ptr(), x_rs, x_hs
+    a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), Qc * K * D, (0 if stages_share_codebook else K * D)
+    a.idx, a.idx_hs, a.idx_rs, a.idx_qs = idx.data_ptr(), int(idx.stride(0)), int(idx.stride(1)), int(idx.stride(2))
+    go_ptr, go_rs, go_hs = None, 0, 0
+    if grad_out is not None:
+        assert grad_out.dtype == torch.float32 and tuple(grad_out.shape) == (H, M, D)
+        if grad_out.stride(-1) != 1:
+            grad_out = grad_out.contiguous()
+        go_ptr = grad_out.data_ptr()
+        go_rs, go_hs = _row_strides(grad_out)
+    ge_ptr = None
+    if grad_sq_err is not None:
+        grad_sq_err = grad_sq_err.to(torch.float64).contiguous()
+        assert grad_sq_err.numel() == Q
+        ge_ptr = grad_sq_err.data_ptr()
+    with torch.cuda.device(x.device):
+        _check(load().vq_quantize_backward_f32(ctypes.byref(a), go_ptr, go_rs, go_hs, ge_ptr, gx.data_ptr(), D, M * D,
+                                               _stream_ptr(x.device)), "vq_quantize_backward_f32")
     return gx

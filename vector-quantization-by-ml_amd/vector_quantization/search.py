@@ -42,6 +42,11 @@ class _NativeBackend:
 
 
     @staticmethod
+    def quantize_backward(x, cb, idx, grad_out, grad_sq_err, *, ste, share):
+        """d/dx of the quantize step in one native pass (vq_quantize_backward_f32)."""
+        return native.quantize_backward(x, cb, idx, grad_out, grad_sq_err, ste=ste, stages_share_codebook=share)
+
+    @staticmethod
     def cross_entropy_backward(x, cb, lse, target_logit, target, coef, *, metric):
         """Fused d/dx of the cross entropy (vq_ce_backward_f32); None when the shape is outside the kernel's range."""
         if x.shape[-1] > native.CE_BACKWARD_MAX_DIM:
@@ -97,6 +102,11 @@ class _QuantizeFn(torch.autograd.Function):
         gx = gcb = None
         need_x = ctx.needs_input_grad[0]
         need_cb = ctx.needs_input_grad[1]
+        fused = getattr(_backend, "quantize_backward", None)
+        if fused is not None and need_x and not need_cb:
+            # one pass over x / grad_out; no host synchronisation (the torch path below inspects g_err on the host)
+            return (fused(x.detach(), cb.detach(), idx, g_out if ctx.ste else None, g_err, ste=ctx.ste, share=ctx.share),
+                    None, None, None, None, None, None, None, None, None)
         if need_x:
             gx = g_out * float(Q) if ctx.ste else torch.zeros_like(x)
         if need_cb:
