@@ -150,6 +150,10 @@ int vq_quantize_backward_f32(const vq_args *a, const float *grad_out, int64_t go
  */
 int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs, int64_t idx_hs,
                           const uint8_t *mask, int H, int64_t M, int K, int D, float *counts, float *sums, void *stream);
+/* The same statistics for every stage of a residual stack in one pass (residual_vq.py:212-233: stage q's Codebook sees the
+ * residual r_q): uses a->x, a->cb (stages cb_qs apart; 0 = shared), a->idx (as written by vq_quantize_f32), H, M, K, D, Q
+ * and VQ_F_STE (train-mode residual rule).  counts [H][Q][K], sums [H][Q][K][D], zeroed by the caller. */
+int vq_ema_accumulate_residual_f32(const vq_args *a, float *counts, float *sums, void *stream);
 int vq_ema_update_f32(float *cluster_size, float *embed_avg, float *embeddings, const float *counts, const float *sums,
                       float *total_scratch, int H, int K, int D, float decay, float eps, int l2norm, void *stream);
 

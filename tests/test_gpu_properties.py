@@ -275,3 +275,29 @@ def test_ema_accumulate_paths_match_index_add(H, M, K, D, masked):
         want_s[h].index_add_(0, idx[h], x[h].double() * w[h][:, None])
     assert torch.equal(counts.double(), want_c)
     torch.testing.assert_close(sums.double(), want_s, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("H,M,K,D,Q,share", [(1, 20000, 256, 256, 4, False), (2, 5000, 64, 300, 3, False),
+                                             (1, 3000, 128, 32, 5, True)])
+def test_ema_accumulate_residual_matches_chain(H, M, K, D, Q, share):
+    """vq_ema_accumulate_residual_f32: per-stage statistics of the residual stack == rebuilding the chain in float64."""
+    from vector_quantization import native
+
+    g = torch.Generator().manual_seed(Q * 100 + K)
+    x = torch.randn((H, M, D), generator=g).cuda()
+    cb = torch.randn((H, 1 if share else Q, K, D), generator=g).cuda() * 0.5
+    r = native.quantize(x, cb, ste=True, stages_share_codebook=share,
+                        idx=torch.empty((H, M, Q), dtype=torch.int64, device="cuda"))
+    idx = r["idx"]
+    counts, sums = native.ema_accumulate_residual(x, cb, idx, ste=True, stages_share_codebook=share)
+    torch.cuda.synchronize()
+    for h in range(H):
+        res = x[h]
+        for q in range(Q):
+            c = cb[h, 0 if share else q][idx[h, :, q]]
+            want_s = torch.zeros((K, D), dtype=torch.float64, device="cuda").index_add_(0, idx[h, :, q], res.double())
+            want_c = torch.bincount(idx[h, :, q], minlength=K).double()
+            assert torch.equal(counts[h, q].double(), want_c)
+            torch.testing.assert_close(sums[h, q].double(), want_s, rtol=1e-5, atol=1e-4)
+            quant = res + (c - res)
+            res = res - quant

@@ -108,7 +108,41 @@ def train_backward():
           f"(includes the (q*w).sum() objective: 2 passes)")
 
 
+def rvq_train():
+    """cfg4 ResidualVQ (Q = 8, K = 1024, D = 256, 65536 tokens): eval forward, train forward with EMA, full step."""
+    dev = "cuda:0"
+    mod = vq.ResidualVQ(dim=256, num_quantizers=8,
+                        codebook_params=CodebookParams(dim=256, codebook_size=1024, threshold_ema_dead_code=0)).to(dev)
+    with torch.no_grad():
+        for i, layer in enumerate(mod.layers):
+            layer._codebook.embeddings.mul_(2.0 ** (-i / 2))
+            layer._codebook.embed_avg.copy_(layer._codebook.embeddings)
+    xs = torch.randn(64, 1024, 256, device=dev, requires_grad=True)
+    w = torch.randn(64, 1024, 256, device=dev)
+
+    def ev():
+        with torch.no_grad():
+            mod(xs)
+
+    def tr():
+        with torch.no_grad():
+            mod(xs)
+
+    def step():
+        xs.grad = None
+        q, i, loss = mod(xs)
+        ((q * w).sum() + loss.sum()).backward()
+
+    mod.eval()
+    t_eval = timed(ev, n=5, warm=2)
+    mod.train()
+    t_train = timed(tr, n=5, warm=2)
+    t_step = timed(step, n=5, warm=2)
+    print(f"ResidualVQ cfg4: eval forward {t_eval:.2f} ms, train forward with EMA {t_train:.2f} ms, forward + backward {t_step:.2f} ms")
+
+
 if __name__ == "__main__":
     main()
     train_steps()
     train_backward()
+    rvq_train()

@@ -555,6 +555,22 @@ int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int6
     return 0;
 }
 
+int vq_ema_accumulate_residual_f32(const vq_args *a, float *counts, float *sums, void *stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (a->M == 0) return 0;
+    if (!a->cb || !a->idx || !counts || !sums) return fail(VQ_E_BADARG, "vq_ema_accumulate_residual: cb / idx / counts / sums is null");
+    long long blocks = (a->M + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vq_ema_accumulate_residual_kernel, dim3((unsigned)blocks, (unsigned)a->H), dim3(256), 0,
+                       (hipStream_t)stream, a->x, (long long)a->x_rs, (long long)a->x_hs, a->cb, (long long)a->cb_hs,
+                       (long long)a->cb_qs, (const long long *)a->idx, (long long)a->idx_rs, (long long)a->idx_hs,
+                       (long long)a->idx_qs, (long long)a->M, a->K, a->D, a->Q, (a->flags & VQ_F_STE) ? 1 : 0, counts, sums);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_ema_accumulate_residual launch");
+    return 0;
+}
+
 int vq_ema_update_f32(float *cluster_size, float *embed_avg, float *embeddings, const float *counts, const float *sums,
                       float *total_scratch, int H, int K, int D, float decay, float eps, int l2norm, void *stream) {
     if (!cluster_size || !embed_avg || !embeddings || !counts || !sums || !total_scratch || H <= 0 || K <= 0 || D <= 0)

@@ -241,11 +241,7 @@ class Codebook(nn.Module):
             from . import native
 
             hits, sums = native.ema_accumulate(flat, idx, k, flat_mask)
-            self._sync_sum(hits)
-            self._sync_sum(sums)
-            codes = self.embeddings.data
-            native.ema_update(self.cluster_size.data, self.embed_avg.data, codes, hits, sums, self.decay,
-                              self.eps_for_smoothing, self.weights_regularization is _unit_rows)
+            self.ema_apply(hits, sums)
         else:  # host tensors only occur under the tests' checker backend
             weights = torch.ones((h, m), dtype=flat.dtype, device=flat.device)
             if flat_mask is not None:
@@ -267,12 +263,27 @@ class Codebook(nn.Module):
         self.reseed_dead_codes(flat)
 
     @torch.no_grad()
-    def reseed_dead_codes(self, flat: torch.Tensor):
+    def ema_apply(self, hits: torch.Tensor, sums: torch.Tensor):
+        """Second half of the EMA step from ready statistics (hits [h, K], sums [h, K, D], contiguous, on the GPU):
+        replica sync, lerp, Laplace smoothing, normalise -- codebooks.py:410-425."""
+        from . import native
+
+        hits, sums = hits.contiguous(), sums.contiguous()
+        self._sync_sum(hits)
+        self._sync_sum(sums)
+        native.ema_update(self.cluster_size.data, self.embed_avg.data, self.embeddings.data, hits, sums, self.decay,
+                          self.eps_for_smoothing, self.weights_regularization is _unit_rows)
+
+    @torch.no_grad()
+    def reseed_dead_codes(self, flat):
+        """``flat`` [h, M, D], or a callable producing it (evaluated only if some code actually expired)."""
         if self.threshold_ema_dead_code == 0:
             return
         dead = self.cluster_size < self.threshold_ema_dead_code
         if not bool(dead.any()):
             return
+        if callable(flat):
+            flat = flat()
         pool = self.weights_regularization(flat)
         for head in range(pool.shape[0]):
             n_dead = int(dead[head].sum().item())

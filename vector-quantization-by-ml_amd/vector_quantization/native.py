@@ -122,6 +122,8 @@ def load():
         lib.vq_ce_backward_f32.restype = ctypes.c_int
         lib.vq_quantize_backward_f32.argtypes = [ap, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp]
         lib.vq_quantize_backward_f32.restype = ctypes.c_int
+        lib.vq_ema_accumulate_residual_f32.argtypes = [ap, _vp, _vp, _vp]
+        lib.vq_ema_accumulate_residual_f32.restype = ctypes.c_int
         lib.vq_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         lib.vq_device_info.restype = ctypes.c_int
         _lib = lib
@@ -133,7 +135,7 @@ EXPORTED_SYMBOLS = (
     "vq_residual_f32", "vq_keys_init", "vq_search_keys_f32", "vq_finalize_keys_f32", "vq_last_error",
     "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32", "vq_similarities_f32", "vq_softmax_stats_f32",
     "vq_ce_backward_f32", "vq_quantize_lse_f32",
-    "vq_quantize_backward_f32",
+    "vq_quantize_backward_f32", "vq_ema_accumulate_residual_f32",
 )
 
 
@@ -474,3 +476,28 @@ def quantize_backward(x: torch.Tensor, cb: torch.Tensor, idx: torch.Tensor, grad
         _check(load().vq_quantize_backward_f32(ctypes.byref(a), go_ptr, go_rs, go_hs, ge_ptr, gx.data_ptr(), D, M * D,
                                                _stream_ptr(x.device)), "vq_quantize_backward_f32")
     return gx
+
+
+def ema_accumulate_residual(x: torch.Tensor, cb: torch.Tensor, idx: torch.Tensor, *, ste: bool = True,
+                            stages_share_codebook: bool = False):
+    """Per-stage EMA statistics of a residual stack in one pass: x [H, M, D], cb [H, Q|1, K, D], idx [H, M, Q] ->
+    (counts [H, Q, K], sums [H, Q, K, D]) where stage q accumulates the residual r_q it quantized."""
+    _require_gpu(x, cb, idx)
+    assert x.dtype == torch.float32 and cb.dtype == torch.float32 and cb.is_contiguous() and idx.dtype == torch.int64
+    H, M, D = x.shape
+    Hc, Qc, K, Dc = cb.shape
+    Q = idx.shape[-1]
+    assert Hc == H and Dc == D and (Qc == Q or (stages_share_codebook and Qc == 1))
+    counts = torch.zeros((H, Q, K), dtype=torch.float32, device=x.device)
+    sums = torch.zeros((H, Q, K, D), dtype=torch.float32, device=x.device)
+    x_rs, x_hs = _row_strides(x)
+    a = VqArgs()
+    a.H, a.Q, a.M, a.K, a.D, a.metric = H, Q, M, K, D, EUCLID
+    a.flags = F_STE if ste else 0
+    a.x, a.x_rs, a.x_hs = x.data_ptr(), x_rs, x_hs
+    a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), Qc * K * D, (0 if stages_share_codebook else K * D)
+    a.idx, a.idx_hs, a.idx_rs, a.idx_qs = idx.data_ptr(), int(idx.stride(0)), int(idx.stride(1)), int(idx.stride(2))
+    with torch.cuda.device(x.device):
+        _check(load().vq_ema_accumulate_residual_f32(ctypes.byref(a), counts.data_ptr(), sums.data_ptr(),
+                                                     _stream_ptr(x.device)), "vq_ema_accumulate_residual_f32")
+    return counts, sums

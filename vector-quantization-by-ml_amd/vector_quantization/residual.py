@@ -165,9 +165,25 @@ class ResidualVQ(nn.Module):
         if training and not freeze_codebook and cb0.ema_update:
             with torch.no_grad():
                 stage_codes = codes[0].expand(Q, -1, -1) if self.shared_codebook else codes[0]
-                residuals = _residual_chain(flat[0].detach(), stage_codes.detach(), idx[0], ste=True)
-                for q, layer in enumerate(self.layers):
-                    layer._codebook.ema_step(residuals[q][None], idx[:, :, q])
+                chain = []
+
+                def residual_rows(q):
+                    if not chain:  # only needed when a code expired, or on host tensors (tests' checker backend)
+                        chain.extend(_residual_chain(flat[0].detach(), stage_codes.detach(), idx[0], ste=True))
+                    return chain[q][None]
+
+                if flat.is_cuda:
+                    # one native pass rebuilds the residual chain from the indices and scatter-adds every stage's statistics
+                    from . import native
+
+                    hits, sums = native.ema_accumulate_residual(flat.detach(), codes.detach().contiguous(), idx, ste=True,
+                                                                stages_share_codebook=self.shared_codebook)
+                    for q, layer in enumerate(self.layers):
+                        layer._codebook.ema_apply(hits[:, q], sums[:, q])
+                        layer._codebook.reseed_dead_codes(lambda q=q: residual_rows(q))
+                else:
+                    for q, layer in enumerate(self.layers):
+                        layer._codebook.ema_step(residual_rows(q), idx[:, :, q])
         return out.reshape(*lead, d), idx.reshape(*lead, Q), losses
 
     def _forward_layers(self, x, mask, freeze_codebook, drop_active, fixed_seed):
