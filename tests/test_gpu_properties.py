@@ -301,3 +301,32 @@ def test_ema_accumulate_residual_matches_chain(H, M, K, D, Q, share):
             torch.testing.assert_close(sums[h, q].double(), want_s, rtol=1e-5, atol=1e-4)
             quant = res + (c - res)
             res = res - quant
+
+
+@pytest.mark.parametrize("kind", ["vq", "rvq"])
+def test_graphed_forward_replays_on_new_data_and_new_weights(oracle, kind):
+    """GraphedForward: one hipGraph launch per forward; new inputs and in-place codebook updates need no re-capture."""
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(0)
+    if kind == "vq":
+        mod = vq.VectorQuantize(dim=64, codebook_params=CodebookParams(dim=64, codebook_size=256)).to(DEV).eval()
+    else:
+        mod = vq.ResidualVQ(dim=64, num_quantizers=3, codebook_params=CodebookParams(dim=64, codebook_size=128)).to(DEV).eval()
+    fast = vq.GraphedForward(mod, torch.randn(32, 256, 64, device=DEV))
+    for step in range(3):
+        if step == 2:  # new weights, same buffers
+            with torch.no_grad():
+                for m in mod.modules():
+                    if isinstance(m, vq.Codebook):
+                        m.embeddings.copy_(torch.randn_like(m.embeddings))
+        x = torch.randn(32, 256, 64, device=DEV)
+        q, i, _ = fast(x)
+        with torch.no_grad():
+            q_ref, i_ref, _ = mod(x)
+        assert torch.equal(i, i_ref) and torch.equal(q, q_ref)
+    with pytest.raises(ValueError):
+        fast(torch.randn(8, 256, 64, device=DEV))
+    with pytest.raises(ValueError):
+        vq.GraphedForward(mod.train(), torch.randn(32, 256, 64, device=DEV))

@@ -146,3 +146,24 @@ if __name__ == "__main__":
     train_steps()
     train_backward()
     rvq_train()
+
+
+def cfg1_latency():
+    """cfg1 (the reference's CPU-sized case): eager module forward vs hipGraph replay."""
+    dev = "cuda:0"
+    mod = vq.VectorQuantize(dim=64, codebook_params=CodebookParams(dim=64, codebook_size=256)).to(dev).eval()
+    x = torch.randn(32, 256, 64, device=dev)
+
+    def eager():
+        with torch.no_grad():
+            mod(x)
+
+    fast = vq.GraphedForward(mod, x)
+    t_e = timed(eager, n=200, warm=20)
+    t_g = timed(lambda: fast(x), n=200, warm=20)
+    print(f"cfg1 VectorQuantize [32,256,64] K=256: eager forward {t_e * 1e3:.1f} us, GraphedForward {t_g * 1e3:.1f} us "
+          f"({8192 / t_g / 1e3:.1f} M rows/s)")
+
+
+if __name__ == "__main__":
+    cfg1_latency()

@@ -11,6 +11,7 @@ The reference's other quantizer families (FSQ, LFQ, latent quantization and thei
 touch the codebook search and are not part of this build.
 """
 from .codebook import Codebook
+from .graphs import GraphedForward
 from .params import AffineParameters, CodebookParams, GumbelParams, KmeansParameters
 from .projection import RandomProjectionQuantizer
 from .quantizer import LossBreakdown, VectorQuantize
@@ -21,6 +22,7 @@ __all__ = [
     "AffineParameters",
     "Codebook",
     "CodebookParams",
+    "GraphedForward",
     "GroupedResidualVQ",
     "GumbelParams",
     "KmeansParameters",
