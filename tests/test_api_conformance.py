@@ -240,8 +240,12 @@ def test_stochastic_sampling_limits_and_seed(device):
     x = torch.randn(1, 500, d, device=device)
     cold = _stochastic_codebook(K, d, 1e-6, device).eval()
     q, ind, _ = cold(x)
-    det, _, _ = search.nearest_with_distance(x.reshape(1, -1, d), cold.embeddings)
-    assert torch.equal(ind.reshape(-1), det.reshape(-1))
+    det, best, _ = search.nearest_with_distance(x.reshape(1, -1, d), cold.embeddings)
+    # similarities / 1e-6 are ~1e6 in fp32 (spacing 0.5), so the O(1) Gumbel noise can only decide between codes whose
+    # distances agree to ~1e-5: the draw is the deterministic winner or tied with it to that precision
+    picked = (x.reshape(-1, d) - cold.embeddings[0][ind.reshape(-1)]).norm(dim=-1)
+    assert float((ind.reshape(-1) == det.reshape(-1)).float().mean()) > 0.98
+    assert bool((picked <= best.reshape(-1) + 1e-4).all())
     assert torch.equal(q, cold.embeddings[0][ind])
     warm = _stochastic_codebook(K, d, 1.0, device).eval()  # eval: no EMA update between the calls; sampling stays on
     torch.manual_seed(7)
