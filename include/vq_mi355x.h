@@ -37,6 +37,7 @@ extern "C" {
 #define VQ_F_STE 1u          /* out = x + (q - x)  (train-mode straight-through, vector_quantize_pytorch.py:273) */
 #define VQ_F_FORCE_SIMPLE 2u /* use the scalar-FMA fallback kernel instead of the MFMA kernel (cross-check)        */
 #define VQ_F_FORCE_SPLIT 4u  /* force the split-K + packed-key path even when the fused path would be chosen        */
+#define VQ_F_SQERR_PER_HEAD 8u /* sq_err (and grad_sq_err of the backward) are [H][Q]: one sum per head and stage     */
 
 /*
  * Packed codebook image (the layout the search kernel streams through LDS).  For one codebook of

@@ -80,6 +80,9 @@ CASES = [
         cb_extra=dict(threshold_ema_dead_code=0)),
     _rvq("ema_rvq_S", 64, 3, 128, (2, 128, 64), "S", training=True, freeze_codebook=False,
          cb_extra=dict(threshold_ema_dead_code=0)),
+    # --- one codebook shared by all stages AND updated by EMA: every stage searches the codebook the previous one rewrote
+    _rvq("ema_rvq_shared_S", 64, 3, 128, (2, 128, 64), "S", training=True, freeze_codebook=False, shared_codebook=True,
+         cb_extra=dict(threshold_ema_dead_code=0)),
     # --- residual stack whose layers use the cross-entropy commitment loss (kwargs forwarded to every VectorQuantize)
     _rvq("rvq_ce_train", 64, 3, 128, (2, 128, 64), "S", training=True,
          vq_extra=dict(commitment_use_cross_entropy_loss=True)),

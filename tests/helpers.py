@@ -22,16 +22,17 @@ class OracleBackend:
     name = "cpu-oracle (tests only)"
 
     @staticmethod
-    def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None, want_lse=False):
+    def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None, want_lse=False,
+                 sq_err_per_head=False):
         res = OracleBackend._quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, share=share,
-                                      want_best=want_best or want_lse, out=out, idx=idx)
+                                      want_best=want_best or want_lse, out=out, idx=idx, per_head=sq_err_per_head)
         if not want_lse:
             return res
         lse, _ = OracleBackend.softmax_stats(x, cb[:, 0], metric=metric, scale=1.0)
         return (*res, lse)
 
     @staticmethod
-    def _quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None):
+    def _quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None, per_head=False):
         H, M, D = x.shape
         Q = idx.shape[-1] if (share and idx is not None) else cb.shape[1]
         xn = np.ascontiguousarray(x.detach().cpu().numpy(), dtype=np.float32)
@@ -39,7 +40,7 @@ class OracleBackend:
         o = np.empty((H, M, D), dtype=np.float32)
         ii = np.empty((H, M, Q), dtype=np.int64)
         bb = np.empty((H, M, Q), dtype=np.float32)
-        err = np.zeros(Q, dtype=np.float64)
+        err = np.zeros((H, Q) if per_head else Q, dtype=np.float64)
         for h in range(H):
             stages = np.stack([cbn[h, 0 if share else q] for q in range(Q)])
             r = vq_oracle.rvq_forward(xn[h], stages, metric, training=ste)
@@ -49,7 +50,10 @@ class OracleBackend:
             else:
                 o[h] = r["out"]
             ii[h], bb[h] = r["idx"], r["best"]
-            err += r["sq_err"]
+            if per_head:
+                err[h] = r["sq_err"]
+            else:
+                err += r["sq_err"]
         out_t = torch.from_numpy(o)
         if out is not None:
             out.copy_(out_t)

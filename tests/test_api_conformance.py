@@ -291,3 +291,40 @@ def test_stochastic_in_vector_quantize_and_residual(device):
     with pytest.raises(NotImplementedError):
         vq.VectorQuantize(dim=8, codebook_params=CodebookParams(
             dim=8, codebook_size=32, gumbel_params=GumbelParams(stochastic=True, straight_through=True))).to(device)(x)
+
+
+# ------------------------------------------------------------------------------- fused vs layer-by-layer training paths
+@pytest.mark.parametrize("kind", ["rvq", "rvq_shared_frozen", "rvq_shared", "grvq"])
+def test_fused_training_forward_equals_layer_by_layer(device, kind):
+    """The fused launches (all stages / groups at once, native per-stage EMA statistics, per-group losses) must leave the
+    same outputs, losses and updated codebooks as walking the layers one VectorQuantize at a time."""
+    import copy
+
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(0)
+    params = CodebookParams(dim=32 if kind != "grvq" else 16, codebook_size=48, threshold_ema_dead_code=0)
+    if kind == "grvq":
+        fused = vq.GroupedResidualVQ(dim=32, groups=2, num_quantizers=3, codebook_params=params).to(device)
+    else:
+        fused = vq.ResidualVQ(dim=32, num_quantizers=3, shared_codebook=kind.startswith("rvq_shared"),
+                              codebook_params=params).to(device)
+    plain = copy.deepcopy(fused)
+    rvqs = plain.rvqs if kind == "grvq" else [plain]
+    for m in [plain] + list(rvqs):
+        m._fusable = lambda *a, **k: False  # layer-by-layer
+    fused.train()
+    plain.train()
+    x = torch.randn(4, 200, 32, device=device)
+    kw = dict(freeze_codebook=True) if kind == "rvq_shared_frozen" else {}
+    a = fused(x, **kw)
+    b = plain(x, **kw)
+    assert torch.equal(a[1], b[1])
+    torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-6)
+    # (a shared codebook under EMA is searched stage by stage on both sides: the module must not fuse that case)
+    for ma, mb in zip(fused.modules(), plain.modules()):
+        if isinstance(ma, vq.Codebook):
+            torch.testing.assert_close(ma.embeddings, mb.embeddings, rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(ma.cluster_size, mb.cluster_size, rtol=1e-6, atol=1e-6)

@@ -105,7 +105,9 @@ def test_gpu_equals_oracle_backend_on_all_cases(oracle):
             search.set_backend(None)
         np.testing.assert_array_equal(got[1].cpu().numpy(), ref[1].numpy(), err_msg=case["name"])
         exact = (not mod.__dict__.get("has_projections", False) and not case.get("codebook_dim") and case["name"] != "proj_mh"
-                 and not (case["training"] and case.get("transform_input") == "l2norm"))  # F.normalize differs GPU vs CPU
+                 and not (case["training"] and case.get("transform_input") == "l2norm")  # F.normalize differs GPU vs CPU
+                 # a shared codebook rewritten by EMA between the stages: its sums are float atomics on the GPU
+                 and not (case.get("shared_codebook") and case["training"] and not case.get("freeze_codebook", True)))
         if exact:
             np.testing.assert_array_equal(got[0].cpu().numpy(), ref[0].numpy(), err_msg=case["name"])
         else:

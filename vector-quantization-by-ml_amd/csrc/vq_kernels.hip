@@ -403,7 +403,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     if (a->M > 0 && !a->idx) return fail(VQ_E_BADARG, "vq_quantize: idx is null");
     if (a->M > 0 && !a->cb) return fail(VQ_E_BADARG, "vq_quantize: natural codebook is null");
     if (a->M == 0) {
-        if (a->sq_err) hipMemsetAsync(a->sq_err, 0, sizeof(double) * a->Q, s);
+        if (a->sq_err) hipMemsetAsync(a->sq_err, 0, sizeof(double) * a->Q * ((a->flags & VQ_F_SQERR_PER_HEAD) ? a->H : 1), s);
         return 0;
     }
     if (!a->workspace || a->workspace_bytes < vq_workspace_bytes(a->H, a->M, a->Q))
@@ -433,6 +433,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         if (a->Q == 1 && wgs * 2 <= cus && ntiles * sub_tiles(DP) >= 8 && ntiles >= 2) fused = false;
         if ((a->flags & VQ_F_FORCE_SPLIT) && a->Q == 1) fused = false;
         if (lse) fused = true;  // the log-sum-exp needs every code of a row in one workgroup
+        if ((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err) fused = true;  // per-head partial sums exist on this path only
     }
 
     if (fused) {
@@ -448,8 +449,10 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         if (rc) return rc;
         if (a->sq_err) {
             const long long rows_per_wg = 32ll * waves;
-            const long long nparts = (long long)a->H * ((a->M + rows_per_wg - 1) / rows_per_wg) * waves;
-            hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(a->Q), dim3(256), 0, s, loss_part, nparts, a->Q, a->sq_err);
+            const long long per_head = ((a->M + rows_per_wg - 1) / rows_per_wg) * waves;
+            const bool by_head = (a->flags & VQ_F_SQERR_PER_HEAD) != 0;
+            hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(a->Q, by_head ? a->H : 1), dim3(256), 0, s, loss_part,
+                               by_head ? per_head : per_head * a->H, a->Q, a->sq_err);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
         }
@@ -457,6 +460,8 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     }
 
     if (a->Q != 1) return fail(VQ_E_UNSUPPORTED, "vq_quantize: residual stages need the MFMA kernel (D <= 512)");
+    if ((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err)
+        return fail(VQ_E_UNSUPPORTED, "vq_quantize: per-head squared errors need the MFMA kernel (D <= 512)");
     rc = vq_keys_init((int64_t *)keys, (int64_t)a->H * a->M, stream);
     if (rc) return rc;
     rc = run_search_keys(a, 0, keys, s);
@@ -492,6 +497,7 @@ int vq_quantize_backward_f32(const vq_args *a, const float *grad_out, int64_t go
     p.idx = (const long long *)a->idx; p.idx_rs = a->idx_rs; p.idx_hs = a->idx_hs; p.idx_qs = a->idx_qs;
     p.go = grad_out; p.go_rs = go_rs; p.go_hs = go_hs;
     p.g_err = grad_sq_err;
+    p.g_err_hs = (a->flags & VQ_F_SQERR_PER_HEAD) ? a->Q : 0;
     p.gx = grad_x; p.gx_rs = gx_rs; p.gx_hs = gx_hs;
     p.M = a->M; p.D = a->D; p.Q = a->Q; p.ste = (a->flags & VQ_F_STE) ? 1 : 0;
     p.vec = (a->D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x) && gx_rs % 4 == 0 && gx_hs % 4 == 0 &&

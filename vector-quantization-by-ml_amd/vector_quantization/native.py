@@ -17,6 +17,7 @@ DOT = 1
 F_STE = 1
 F_FORCE_SIMPLE = 2
 F_FORCE_SPLIT = 4
+F_SQERR_PER_HEAD = 8
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get(
@@ -198,7 +199,7 @@ def _row_strides(t: torch.Tensor):
 def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bool = False, want_out: bool = True,
              want_sq_err: bool = False, want_best: bool = True, packed: torch.Tensor | None = None,
              stages_share_codebook: bool = False, flags: int = 0, out: torch.Tensor | None = None,
-             idx: torch.Tensor | None = None, want_lse: bool = False):
+             idx: torch.Tensor | None = None, want_lse: bool = False, sq_err_per_head: bool = False):
     """The hot path through the C ABI.
 
     x   [H, M, D] fp32 (rows may be strided, last dim contiguous)
@@ -239,11 +240,11 @@ def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bo
         o_rs, o_hs = _row_strides(out)
     else:
         out, o_rs, o_hs = None, 0, 0
-    sq_err = torch.empty((Q,), dtype=torch.float64, device=dev) if want_sq_err else None
+    sq_err = torch.empty((H, Q) if sq_err_per_head else (Q,), dtype=torch.float64, device=dev) if want_sq_err else None
     ws = _workspace(H, M, Q, dev)
     a = VqArgs()
     a.H, a.Q, a.M, a.K, a.D, a.metric = H, Q, M, K, D, metric
-    a.flags = flags | (F_STE if ste else 0)
+    a.flags = flags | (F_STE if ste else 0) | (F_SQERR_PER_HEAD if (sq_err_per_head and want_sq_err) else 0)
     a.x, a.x_rs, a.x_hs = x.data_ptr(), x_rs, x_hs
     a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), Qc * K * D, (0 if stages_share_codebook else K * D)
     a.packed, a.pk_hs, a.pk_qs = packed.data_ptr(), Qc * pf, (0 if stages_share_codebook else pf)
@@ -443,7 +444,8 @@ def ce_backward(x: torch.Tensor, cb: torch.Tensor, lse: torch.Tensor, target_log
 
 
 def quantize_backward(x: torch.Tensor, cb: torch.Tensor, idx: torch.Tensor, grad_out: torch.Tensor | None,
-                      grad_sq_err: torch.Tensor | None, *, ste: bool, stages_share_codebook: bool = False) -> torch.Tensor:
+                      grad_sq_err: torch.Tensor | None, *, ste: bool, stages_share_codebook: bool = False,
+                      sq_err_per_head: bool = False) -> torch.Tensor:
     """d/dx of the quantize step in one pass: x [H, M, D] (strided rows ok), cb [H, Q|1, K, D], idx [H, M, Q] (any
     strides), grad_out [H, M, D] | None, grad_sq_err [Q] float64 | None  ->  grad_x [H, M, D] contiguous."""
     _require_gpu(x, cb, idx, grad_out, grad_sq_err)
@@ -456,7 +458,7 @@ def quantize_backward(x: torch.Tensor, cb: torch.Tensor, idx: torch.Tensor, grad
     x_rs, x_hs = _row_strides(x)
     a = VqArgs()
     a.H, a.Q, a.M, a.K, a.D, a.metric = H, Q, M, K, D, EUCLID
-    a.flags = F_STE if ste else 0
+    a.flags = (F_STE if ste else 0) | (F_SQERR_PER_HEAD if sq_err_per_head else 0)
     a.x, a.x_rs, a.x_hs = x.data_ptr(), x_rs, x_hs
     a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), Qc * K * D, (0 if stages_share_codebook else K * D)
     a.idx, a.idx_hs, a.idx_rs, a.idx_qs = idx.data_ptr(), int(idx.stride(0)), int(idx.stride(1)), int(idx.stride(2))
@@ -470,7 +472,7 @@ def quantize_backward(x: torch.Tensor, cb: torch.Tensor, idx: torch.Tensor, grad
     ge_ptr = None
     if grad_sq_err is not None:
         grad_sq_err = grad_sq_err.to(torch.float64).contiguous()
-        assert grad_sq_err.numel() == Q
+        assert grad_sq_err.numel() == (H * Q if sq_err_per_head else Q)
         ge_ptr = grad_sq_err.data_ptr()
     with torch.cuda.device(x.device):
         _check(load().vq_quantize_backward_f32(ctypes.byref(a), go_ptr, go_rs, go_hs, ge_ptr, gx.data_ptr(), D, M * D,

@@ -130,7 +130,11 @@ class ResidualVQ(nn.Module):
         assert indices is None, "cross-entropy to given indices is not supported (asserted in the reference as well)"
         x = self.project_in(x)
         drop_active = self.training and self.quantize_dropout
-        if self._fusable(x, mask, drop_active):
+        # a SHARED codebook that is being updated must be searched stage by stage: in the reference every layer's forward
+        # rewrites it (EMA) before the next layer looks at it (residual_vq.py:212-233, codebooks.py:399-426)
+        shared_and_moving = (self.shared_codebook and self.training and not freeze_codebook
+                             and self.layers[0]._codebook.ema_update)
+        if not shared_and_moving and self._fusable(x, mask, drop_active):
             quantized, all_indices, all_losses = self._forward_fused(x, freeze_codebook)
         else:
             quantized, all_indices, all_losses = self._forward_layers(x, mask, freeze_codebook, drop_active,
@@ -293,19 +297,35 @@ class GroupedResidualVQ(nn.Module):
         )  # [G, Q, K, d]
         want_loss = training and first.has_commitment_loss
         q_buf = torch.empty((rows, G, d), dtype=torch.float32, device=xc.device)
-        out, idx, sq_err_unused = search.quantize_rows(flat, codes, metric=cb0.metric, ste=training, want_sq_err=False,
-                                                       out=q_buf.permute(1, 0, 2))
+        # one launch for all groups and stages; squared errors come back per group (head) and stage
+        out, idx, sq_err = search.quantize_rows(flat, codes, metric=cb0.metric, ste=training, want_sq_err=want_loss,
+                                                out=q_buf.permute(1, 0, 2), sq_err_per_head=True)
         losses = torch.zeros((G, 1, Q), dtype=torch.float32, device=xc.device)
-        if want_loss or (training and not freeze_codebook and cb0.ema_update):
+        if want_loss:
+            losses = losses + (sq_err / (rows * d)).to(torch.float32)[:, None, :] * first.commitment_weight
+        if training and not freeze_codebook and cb0.ema_update:
             with torch.no_grad():
+                chains = {}
+
+                def residual_rows(g, q):
+                    if g not in chains:  # only when a code expired, or on host tensors (tests' checker backend)
+                        chains[g] = _residual_chain(flat[g].detach(), codes[g].detach(), idx[g], ste=True)
+                    return chains[g][q][None]
+
+                if flat.is_cuda:
+                    from . import native
+
+                    hits, sums = native.ema_accumulate_residual(flat.detach(), codes.detach().contiguous(), idx, ste=True)
                 for g, rvq in enumerate(self.rvqs):
-                    residuals = _residual_chain(flat[g].detach(), codes[g].detach(), idx[g], ste=True)
                     for q, layer in enumerate(rvq.layers):
-                        if want_loss:
-                            c = codes[g, q][idx[g, :, q]]
-                            losses[g, 0, q] = ((c - residuals[q]) ** 2).mean() * first.commitment_weight
-                        if training and not freeze_codebook and layer._codebook.ema_update:
-                            layer._codebook.ema_step(residuals[q][None], idx[g:g + 1, :, q])
+                        cbq = layer._codebook
+                        if not cbq.ema_update:
+                            continue
+                        if flat.is_cuda:
+                            cbq.ema_apply(hits[g:g + 1, q], sums[g:g + 1, q])
+                            cbq.reseed_dead_codes(lambda g=g, q=q: residual_rows(g, q))
+                        else:
+                            cbq.ema_step(residual_rows(g, q), idx[g:g + 1, :, q])
         quantized = q_buf.view(*lead, self.dim)
         all_indices = idx.reshape(G, *lead, Q)
         ret = (quantized, all_indices, losses)

@@ -21,11 +21,13 @@ class _NativeBackend:
     name = "hip-gfx950"
 
     @staticmethod
-    def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None, want_lse=False):
+    def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None, want_lse=False,
+                 sq_err_per_head=False):
         """-> (out, idx, best, sq_err) and, with ``want_lse`` (single stage), a fifth element: the per-row log-sum-exp
         of the similarities from the same sweep (vq_quantize_lse_f32)."""
         r = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, want_best=want_best or want_lse,
-                            stages_share_codebook=share, out=out, idx=idx, want_lse=want_lse)
+                            stages_share_codebook=share, out=out, idx=idx, want_lse=want_lse,
+                            sq_err_per_head=sq_err_per_head)
         if want_lse:
             return r["out"], r["idx"], r["best"], r["sq_err"], r["lse"]
         return r["out"], r["idx"], r["best"], r["sq_err"]
@@ -42,9 +44,10 @@ class _NativeBackend:
 
 
     @staticmethod
-    def quantize_backward(x, cb, idx, grad_out, grad_sq_err, *, ste, share):
+    def quantize_backward(x, cb, idx, grad_out, grad_sq_err, *, ste, share, sq_err_per_head=False):
         """d/dx of the quantize step in one native pass (vq_quantize_backward_f32)."""
-        return native.quantize_backward(x, cb, idx, grad_out, grad_sq_err, ste=ste, stages_share_codebook=share)
+        return native.quantize_backward(x, cb, idx, grad_out, grad_sq_err, ste=ste, stages_share_codebook=share,
+                                        sq_err_per_head=sq_err_per_head)
 
     @staticmethod
     def cross_entropy_backward(x, cb, lse, target_logit, target, coef, *, metric):
@@ -80,14 +83,21 @@ class _QuantizeFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out_buf, idx_buf, want_lse=False):
+    def forward(ctx, x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out_buf, idx_buf, want_lse=False,
+                per_head=False):
+        extra = {}
+        if want_lse:
+            extra["want_lse"] = True
+        if per_head:
+            extra["sq_err_per_head"] = True
         res = _backend.quantize(x.detach(), cb.detach(), metric=metric, ste=ste, want_sq_err=want_sq_err, share=share,
-                                out=out_buf, idx=idx_buf, **({"want_lse": True} if want_lse else {}))
+                                out=out_buf, idx=idx_buf, **extra)
         out, idx, best, sq_err = res[:4]
         ctx.save_for_backward(x, cb, idx)
-        ctx.ste, ctx.share, ctx.cb_err = ste, share, codebook_grad_from_err
+        ctx.ste, ctx.share, ctx.cb_err, ctx.per_head = ste, share, codebook_grad_from_err, per_head
         if sq_err is None:
-            sq_err = torch.zeros(idx.shape[-1], dtype=torch.float64, device=x.device)
+            sq_err = torch.zeros((x.shape[0], idx.shape[-1]) if per_head else idx.shape[-1], dtype=torch.float64,
+                                 device=x.device)
         if want_lse:
             ctx.mark_non_differentiable(idx, best, res[4])
             return out, idx, sq_err, best, res[4]
@@ -105,8 +115,9 @@ class _QuantizeFn(torch.autograd.Function):
         fused = getattr(_backend, "quantize_backward", None)
         if fused is not None and need_x and not need_cb:
             # one pass over x / grad_out; no host synchronisation (the torch path below inspects g_err on the host)
-            return (fused(x.detach(), cb.detach(), idx, g_out if ctx.ste else None, g_err, ste=ctx.ste, share=ctx.share),
-                    None, None, None, None, None, None, None, None, None)
+            return (fused(x.detach(), cb.detach(), idx, g_out if ctx.ste else None, g_err, ste=ctx.ste, share=ctx.share,
+                          **({"sq_err_per_head": True} if ctx.per_head else {})),
+                    None, None, None, None, None, None, None, None, None, None)
         if need_x:
             gx = g_out * float(Q) if ctx.ste else torch.zeros_like(x)
         if need_cb:
@@ -120,7 +131,7 @@ class _QuantizeFn(torch.autograd.Function):
                 i = idx[..., q]
                 c = cq[harange, i]  # [H, M, D]
                 if has_err:
-                    w = g_err[q].to(x.dtype)
+                    w = (g_err[:, q, None, None] if ctx.per_head else g_err[q]).to(x.dtype)
                     if need_x:
                         gx = gx + 2.0 * w * (r - c)
                     if need_cb and ctx.cb_err:
@@ -130,18 +141,20 @@ class _QuantizeFn(torch.autograd.Function):
                     gcb[:, 0 if ctx.share else q].index_put_((harange.expand_as(i), i), g_out, accumulate=True)
                 quant = r + (c - r) if ctx.ste else c
                 r = r - quant
-        return gx, gcb, None, None, None, None, None, None, None, None
+        return gx, gcb, None, None, None, None, None, None, None, None, None
 
 
 def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bool = False,
                   want_sq_err: bool = False, share: bool = False, codebook_grad_from_err: bool = False,
-                  out: Optional[torch.Tensor] = None, idx: Optional[torch.Tensor] = None, want_lse: bool = False):
+                  out: Optional[torch.Tensor] = None, idx: Optional[torch.Tensor] = None, want_lse: bool = False,
+                  sq_err_per_head: bool = False):
     """x [H, M, D] (strided rows allowed), cb [H, Q, K, D] contiguous ([H, 1, K, D] when ``share``; the number
     of stages is then ``idx.shape[-1]``).  ``out`` / ``idx`` may be pre-allocated (strided) destination views.
 
     Returns (out [H, M, D], idx [H, M, Q] int64, sq_err [Q] float64 or None); with ``want_lse`` (single stage) a fourth
     element: dict(best [H, M, 1], lse [H, M]) -- the winner's distance / similarity and the log-sum-exp of the row's
     similarities, both from the same sweep (what the cross-entropy commitment loss needs).
+    ``sq_err_per_head``: sq_err is [H, Q] (one sum per head: GroupedResidualVQ reports a loss per group).
     """
     if x.dtype != torch.float32:
         x = x.float()
@@ -149,7 +162,8 @@ def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, st
         cb = cb.contiguous()
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or cb.requires_grad)
     if needs_grad:
-        res = _QuantizeFn.apply(x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out, idx, want_lse)
+        res = _QuantizeFn.apply(x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out, idx, want_lse,
+                                sq_err_per_head)
         out, idx, sq_err = res[:3]
         if want_lse:
             return out, idx, (sq_err if want_sq_err else None), dict(best=res[3], lse=res[4])
@@ -159,7 +173,8 @@ def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, st
                                                         share=share, out=out, idx=idx, want_lse=True)
         return out, idx, sq_err, dict(best=best, lse=lse)
     out, idx, _best, sq_err = _backend.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, share=share,
-                                                out=out, idx=idx)
+                                                out=out, idx=idx,
+                                                **({"sq_err_per_head": True} if sq_err_per_head else {}))
     return out, idx, sq_err
 
 
