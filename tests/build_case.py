@@ -87,7 +87,7 @@ def build(case, arrays=None, device="cpu"):
         dim, K, Q, G = case["dim"], case["K"], case["Q"], case["groups"]
         d = dim // G
         mod = vq.GroupedResidualVQ(dim=dim, groups=G, num_quantizers=Q,
-                                   codebook_params=CodebookParams(dim=d, codebook_size=K))
+                                   codebook_params=CodebookParams(dim=d, codebook_size=K, **case.get("cb_extra", {})))
         cbs = []
         with torch.no_grad():
             for g, rvq in enumerate(mod.rvqs):
@@ -95,6 +95,7 @@ def build(case, arrays=None, device="cpu"):
                 cbs.append(c)
                 for i, layer in enumerate(rvq.layers):
                     layer._codebook.embeddings.copy_(c[i][None])
+                    layer._codebook.embed_avg.copy_(c[i][None])
         cb = torch.stack(cbs)
     else:
         raise ValueError(kind)

@@ -58,7 +58,12 @@ def compare(case, arrays, meta, outputs, x, cb, mod=None):
         s = float(quantize.double().sum())
         assert abs(s - meta["q_checksum"][0]) <= 1e-5 * max(1.0, meta["q_checksum"][1]), (s, meta["q_checksum"])
     if "ema_embeddings" in arrays and mod is not None:
-        if case["kind"] == "rvq":
+        if case["kind"] == "grvq":
+            layers = [l for rvq in mod.rvqs for l in rvq.layers]
+            emb = torch.stack([l._codebook.embeddings for l in layers])
+            avg = torch.stack([l._codebook.embed_avg for l in layers])
+            cs = torch.stack([l._codebook.cluster_size for l in layers])
+        elif case["kind"] == "rvq":
             emb = torch.stack([l._codebook.embeddings for l in mod.layers])
             avg = torch.stack([l._codebook.embed_avg for l in mod.layers])
             cs = torch.stack([l._codebook.cluster_size for l in mod.layers])

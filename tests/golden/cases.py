@@ -70,6 +70,9 @@ CASES = [
     _rvq("rvq_shared", 64, 4, 256, (2, 128, 64), "S", shared_codebook=True),
     _rvq("rvq_allcodes", 32, 3, 64, (2, 20, 32), "S", return_all_codes=True),
     dict(name="grvq", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=False),
+    dict(name="grvq_train", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=True),
+    dict(name="grvq_ema", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=True,
+         freeze_codebook=False, cb_extra=dict(threshold_ema_dead_code=0)),
     # --- training-state step after the hot path: EMA update, no dead-code re-seeding (RNG) --
     _vq("ema_S", 64, 256, (8, 256, 64), "S", training=True, freeze_codebook=False, cb_extra=dict(threshold_ema_dead_code=0)),
     _vq("ema_mh_S", 128, 128, (4, 64, 128), "S", training=True, freeze_codebook=False, heads=2, codebook_dim=64,

@@ -267,7 +267,7 @@ def run_rvq(ref, ref_cb, c):
 def run_grvq(ref, ref_cb, c):
     dim, K, Q, G = c["dim"], c["K"], c["Q"], c["groups"]
     d = dim // G
-    params = ref_cb.CodebookParams(dim=d, codebook_size=K)
+    params = ref_cb.CodebookParams(dim=d, codebook_size=K, **c.get("cb_extra", {}))
     mod = ref.GroupedResidualVQ(dim=dim, groups=G, num_quantizers=Q, codebook_params=params)
     all_cbs = []
     with torch.no_grad():
@@ -276,14 +276,25 @@ def run_grvq(ref, ref_cb, c):
             all_cbs.append(cbs)
             for i, layer in enumerate(rvq.layers):
                 layer._codebook.embeddings.copy_(cbs[i][None])
+                layer._codebook.embed_avg.copy_(cbs[i][None])
     x = make_x(c["x_shape"], c["cls"])
-    mod.eval()
+    kwargs = {}
+    if c["training"]:
+        mod.train()
+        kwargs["freeze_codebook"] = c.get("freeze_codebook", True)
+    else:
+        mod.eval()
     with torch.no_grad():
-        q, idx, losses = mod(x)
+        q, idx, losses = mod(x, **kwargs)
     arrays = dict(idx=idx.numpy().astype(np.int32), loss=losses.detach().numpy().astype(np.float32),
                   q_full=q.detach().numpy().copy())
     rows, vals = sample_rows(q, q.shape[-1])
     arrays["q_rows"], arrays["q_vals"] = rows, vals
+    if c["training"] and not c.get("freeze_codebook", True):
+        layers = [l for rvq in mod.rvqs for l in rvq.layers]
+        arrays["ema_embeddings"] = torch.stack([l._codebook.embeddings for l in layers]).detach().numpy().copy()
+        arrays["ema_embed_avg"] = torch.stack([l._codebook.embed_avg for l in layers]).detach().numpy().copy()
+        arrays["ema_cluster_size"] = torch.stack([l._codebook.cluster_size for l in layers]).detach().numpy().copy()
     meta = dict(x_checksum=checksum(x), cb_checksum=checksum(torch.stack(all_cbs)), q_checksum=checksum(q),
                 q_shape=list(q.shape), idx_shape=list(idx.shape))
     return arrays, meta
