@@ -75,7 +75,7 @@ def build(case, arrays=None, device="cpu"):
         shared = case.get("shared_codebook", False)
         mod = vq.ResidualVQ(dim=dim, num_quantizers=Q,
                             codebook_params=CodebookParams(dim=dim, codebook_size=K, **case.get("cb_extra", {})),
-                            shared_codebook=shared, **case.get("vq_extra", {}))
+                            shared_codebook=shared, **case.get("vq_extra", {}), **case.get("rvq_extra", {}))
         cb = make_rvq_codebooks(Q, K, dim, case["cls"])
         with torch.no_grad():
             for i, layer in enumerate(mod.layers):
@@ -83,6 +83,7 @@ def build(case, arrays=None, device="cpu"):
                 layer._codebook.embed_avg.copy_(cb[0 if shared else i][None])
         if case.get("return_all_codes", False):
             kwargs["return_all_codes"] = True
+        kwargs.update(case.get("fwd_extra", {}))
     elif kind == "grvq":
         dim, K, Q, G = case["dim"], case["K"], case["Q"], case["groups"]
         d = dim // G

@@ -70,6 +70,17 @@ CASES = [
     _rvq("rvq_shared", 64, 4, 256, (2, 128, 64), "S", shared_codebook=True),
     _rvq("rvq_allcodes", 32, 3, 64, (2, 20, 32), "S", return_all_codes=True),
     dict(name="grvq", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=False),
+    _vq("ema_mh_shared_S", 128, 128, (4, 64, 128), "S", training=True, freeze_codebook=False, heads=2, codebook_dim=64,
+        cb_extra=dict(threshold_ema_dead_code=0)),
+    _vq("ema_chfirst_img_S", 32, 64, (2, 32, 8, 8), "S", training=True, freeze_codebook=False, channel_last=False,
+        cb_extra=dict(threshold_ema_dead_code=0)),
+    # --- quantize dropout (python's random.Random(seed): reproducible): dropped stages report index -1 and loss 0
+    _rvq("rvq_dropout", 64, 6, 64, (2, 40, 64), "S", training=True, return_all_codes=True,
+         rvq_extra=dict(quantize_dropout=True, quantize_dropout_cutoff_index=1, quantize_dropout_multiple_of=2),
+         fwd_extra=dict(rand_quantize_dropout_fixed_seed=5)),
+    _rvq("rvq_dropout_b", 64, 6, 64, (2, 40, 64), "S", training=True,
+         rvq_extra=dict(quantize_dropout=True, quantize_dropout_cutoff_index=0, quantize_dropout_multiple_of=1),
+         fwd_extra=dict(rand_quantize_dropout_fixed_seed=11)),
     dict(name="grvq_train", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=True),
     dict(name="grvq_ema", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=True,
          freeze_codebook=False, cb_extra=dict(threshold_ema_dead_code=0)),

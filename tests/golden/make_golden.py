@@ -230,7 +230,7 @@ def run_rvq(ref, ref_cb, c):
     params = ref_cb.CodebookParams(dim=dim, codebook_size=K, **c.get("cb_extra", {}))
     shared = c.get("shared_codebook", False)
     mod = ref.ResidualVQ(dim=dim, num_quantizers=Q, codebook_params=params, shared_codebook=shared,
-                         **c.get("vq_extra", {}))
+                         **c.get("vq_extra", {}), **c.get("rvq_extra", {}))
     cbs = make_rvq_codebooks(Q, K, dim, c["cls"])
     with torch.no_grad():
         for i, layer in enumerate(mod.layers):
@@ -245,6 +245,7 @@ def run_rvq(ref, ref_cb, c):
         mod.eval()
     if c.get("return_all_codes", False):
         kwargs["return_all_codes"] = True
+    kwargs.update(c.get("fwd_extra", {}))
     with torch.no_grad():
         out = mod(x, **kwargs)
     q, idx, losses = out[:3]
