@@ -42,10 +42,15 @@ def build(case, arrays=None, device="cpu"):
         codebook_dim = case.get("codebook_dim", None)
         d = codebook_dim if codebook_dim is not None else dim
         h = heads if separate else 1
+        cb_extra = dict(case.get("cb_extra", {}))
+        if "kmeans_iter" in cb_extra:
+            from vector_quantization.codebooks import KmeansParameters
+
+            cb_extra["kmeans_params"] = KmeansParameters(iter=cb_extra.pop("kmeans_iter"), sync=False)
         params = CodebookParams(dim=d, codebook_size=K, use_cosine_sim=case.get("use_cosine_sim", False),
                                 transform_input=case.get("transform_input", "identity"),
                                 weights_regularization=case.get("weights_regularization", "identity"),
-                                **case.get("cb_extra", {}))
+                                **cb_extra)
         extra = dict(case.get("vq_extra", {}))
         if "inplace_sgd_lr" in case:
             extra["in_place_codebook_optimizer"] = lambda params: torch.optim.SGD(params, lr=case["inplace_sgd_lr"])

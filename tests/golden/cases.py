@@ -81,6 +81,15 @@ CASES = [
     _rvq("rvq_dropout_b", 64, 6, 64, (2, 40, 64), "S", training=True,
          rvq_extra=dict(quantize_dropout=True, quantize_dropout_cutoff_index=0, quantize_dropout_multiple_of=1),
          fwd_extra=dict(rand_quantize_dropout_fixed_seed=11)),
+    # --- RNG-dependent bookkeeping, pinned on the CPU only (torch.manual_seed before the forward; the sampling consumes the
+    #     generator in the reference's order): k-means seeding of the codebook from the first batch, dead-code re-seeding
+    _vq("kmeans_init_S", 32, 16, (4, 64, 32), "S", training=True, freeze_codebook=False, cpu_only=True, forward_seed=123,
+        cb_extra=dict(initialization_by_kmeans=True, threshold_ema_dead_code=0, kmeans_iter=5)),
+    _vq("kmeans_init_cos_S", 32, 16, (4, 64, 32), "S", training=True, freeze_codebook=False, cpu_only=True, forward_seed=123,
+        use_cosine_sim=True, transform_input="l2norm", weights_regularization="l2norm",
+        cb_extra=dict(initialization_by_kmeans=True, threshold_ema_dead_code=0, kmeans_iter=5)),
+    _vq("dead_code_expiry_S", 32, 300, (4, 64, 32), "S", training=True, freeze_codebook=False, cpu_only=True, forward_seed=123,
+        cb_extra=dict(threshold_ema_dead_code=2)),
     dict(name="grvq_train", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=True),
     dict(name="grvq_ema", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=True,
          freeze_codebook=False, cb_extra=dict(threshold_ema_dead_code=0)),

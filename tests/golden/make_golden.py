@@ -66,11 +66,14 @@ def run_vq(ref, ref_cb, c):
     d = codebook_dim if codebook_dim is not None else dim
     h = heads if separate else 1
     use_cos = c.get("use_cosine_sim", False)
+    cb_extra = dict(c.get("cb_extra", {}))
+    if "kmeans_iter" in cb_extra:
+        cb_extra["kmeans_params"] = ref_cb.KmeansParameters(iter=cb_extra.pop("kmeans_iter"), sync=False)
     params = ref_cb.CodebookParams(
         dim=d, codebook_size=K, use_cosine_sim=use_cos,
         transform_input=c.get("transform_input", "identity"),
         weights_regularization=c.get("weights_regularization", "identity"),
-        **c.get("cb_extra", {}),
+        **cb_extra,
     )
     torch.manual_seed(777)
     mod = ref.VectorQuantize(dim=dim, codebook_params=params, codebook_dim=codebook_dim, heads=heads,
@@ -99,6 +102,8 @@ def run_vq(ref, ref_cb, c):
         kwargs["freeze_codebook"] = c.get("freeze_codebook", True)
     else:
         mod.eval()
+    if "forward_seed" in c:
+        torch.manual_seed(c["forward_seed"])
     with torch.no_grad():
         q, idx, loss = mod(x, **kwargs)
     arrays = dict(idx=idx.numpy().astype(np.int32), loss=loss.detach().numpy().astype(np.float32),

@@ -24,7 +24,10 @@ def _native_backend():
     yield
 
 
-@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+GPU_CASES = [c for c in CASES if not c.get("cpu_only", False)]  # (host-RNG-dependent bookkeeping is pinned on the CPU)
+
+
+@pytest.mark.parametrize("case", GPU_CASES, ids=[c["name"] for c in GPU_CASES])
 def test_module_matches_reference_golden_on_gpu(case):
     arrays, meta = load_golden(case["name"])
     mod, x, kwargs, cb = build(case, arrays, device="cuda:0")
@@ -89,7 +92,7 @@ def test_gpu_equals_oracle_backend_on_all_cases(oracle):
     from helpers import OracleBackend
     from vector_quantization import search
 
-    for case in CASES:
+    for case in GPU_CASES:
         if case["name"] in ("cfg5_S",):
             continue
         arrays, _ = load_golden(case["name"])

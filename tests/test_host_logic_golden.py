@@ -33,6 +33,10 @@ def test_module_matches_reference_golden(case):
     assert ok, f"input regeneration drifted: {got} vs {meta['x_checksum']}"
     ok, got = checksum_close(cb, meta["cb_checksum"])
     assert ok, f"codebook regeneration drifted: {got} vs {meta['cb_checksum']}"
+    if "forward_seed" in case:
+        import torch
+
+        torch.manual_seed(case["forward_seed"])
     outputs = mod(x, **kwargs)
     compare(case, arrays, meta, outputs, x, cb, mod)
 
