@@ -166,6 +166,14 @@ LOSS_CASES = [
 _LEARN = dict(learnable_codebook=True, ema_update=False)
 
 LOSS_CASES += [
+    # the standard training step with the EMA update running: the backward of the MSE commitment loss must use the codes the
+    # forward searched, not the ones the EMA step wrote afterwards
+    _vql("mse_commit_ema", 64, 256, (4, 64, 64), freeze_codebook=False, backprop_q=True, cb_extra=dict(threshold_ema_dead_code=0)),
+    _vql("mse_commit_ema_mh", 64, 128, (2, 50, 64), freeze_codebook=False, backprop_q=True, heads=2, codebook_dim=32,
+         separate_codebook_per_head=True, cb_extra=dict(threshold_ema_dead_code=0)),
+]
+
+LOSS_CASES += [
     # --- learnable codebook options of the quantize step: gradient scaling rule and the in-place optimizer ------------
     _vql("learnable", 64, 256, (4, 64, 64), cb_extra=_LEARN, freeze_codebook=False, backprop_q=True),
     _vql("sync_update", 64, 256, (4, 64, 64), cb_extra=_LEARN, freeze_codebook=False, backprop_q=True,

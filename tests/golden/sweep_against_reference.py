@@ -92,6 +92,42 @@ def run(kind, ctor, x, fwd, mode):
         compare(f"state[{k}]", sm[k], sr[k], tol=1e-4)
 
 
+def run_grad(kind, ctor, x, fwd, mode):
+    """Autograd parity: d(objective)/dx and parameter gradients (projections, learnable codebooks)."""
+    torch.manual_seed(7)
+    cb_kw = dict(ctor.pop("cb"))
+    r = getattr(ref, kind)(codebook_params=ref_cb.CodebookParams(**cb_kw), **ctor)
+    m = getattr(mine, kind)(codebook_params=MineParams(**cb_kw), **ctor)
+    m.load_state_dict(r.state_dict())
+    kw = dict(fwd)
+    if mode == "train_frozen":
+        kw["freeze_codebook"] = True
+    if "mask" in kw:
+        kw["mask"] = torch.arange(x.shape[1])[None, :] < torch.tensor([x.shape[1], max(1, x.shape[1] // 2)])[:, None]
+    grads = []
+    for mod in (r, m):
+        mod.train() if mode != "eval" else mod.eval()
+        xs = x.clone().requires_grad_(True)
+        out = mod(xs, **kw)
+        w = torch.randn(out[0].shape, generator=torch.Generator().manual_seed(5))
+        objective = (out[0] * w).sum() + out[2].sum() * 1.5
+        if not objective.requires_grad:
+            grads.append(None)
+            continue
+        objective.backward()
+        grads.append((xs.grad, {k: p.grad for k, p in mod.named_parameters()}))
+    if grads[0] is None or grads[1] is None:
+        assert grads[0] is None and grads[1] is None, "only one side has a differentiable objective"
+        return
+    compare("x.grad", grads[1][0] if grads[1][0] is not None else torch.zeros_like(x),
+            grads[0][0] if grads[0][0] is not None else torch.zeros_like(x))
+    for k, g in grads[0][1].items():
+        gm = grads[1][1][k]
+        if g is None and gm is None:
+            continue
+        compare(f"grad[{k}]", gm if gm is not None else torch.zeros_like(g), g if g is not None else torch.zeros_like(gm), tol=1e-4)
+
+
 def main():
     cases = []
     noexp = dict(threshold_ema_dead_code=0)
@@ -126,6 +162,30 @@ def main():
         cases.append(("GroupedResidualVQ", dict(dim=32, groups=groups, num_quantizers=3,
                                                 cb=dict(dim=32 // groups, codebook_size=24, **noexp)), (2, 30, 32), {}))
     n_bad = 0
+    # ---- autograd parity on a subset (no given indices: that path returns two values)
+    learn = dict(learnable_codebook=True, ema_update=False)
+    grad_cases = [c for c in cases if "given_indices" not in c[3] and not c[1].get("quantize_dropout")][::3]
+    for cdim in (None, 16):
+        grad_cases.append(("VectorQuantize", dict(dim=32, codebook_dim=cdim, cb=dict(dim=cdim or 32, codebook_size=40, **learn)),
+                           (2, 30, 32), {}))
+        grad_cases.append(("VectorQuantize", dict(dim=32, codebook_dim=cdim, sync_update_v=0.3,
+                                                  cb=dict(dim=cdim or 32, codebook_size=40, **learn)), (2, 30, 32), {}))
+        grad_cases.append(("ResidualVQ", dict(dim=32, num_quantizers=3, codebook_dim=cdim,
+                                              cb=dict(dim=cdim or 32, codebook_size=40, **learn)), (2, 30, 32), {}))
+    n_grad = 0
+    for kind, ctor, shape, fwd in grad_cases:
+        for mode in ("eval", "train_frozen", "train_ema"):
+            if mode == "train_ema" and ctor["cb"].get("learnable_codebook"):
+                mode = "train_learn"
+            x = torch.randn(*shape, generator=torch.Generator().manual_seed(11))
+            label = f"GRAD {kind} {({k: v for k, v in ctor.items() if k != 'cb'})} cb={ctor['cb']} x{shape} {fwd} {mode}"
+            n_grad += 1
+            try:
+                run_grad(kind, {k: (dict(v) if isinstance(v, dict) else v) for k, v in ctor.items()}, x, fwd, mode)
+            except Exception as e:  # noqa: BLE001
+                n_bad += 1
+                print("MISMATCH", label, "->", type(e).__name__, str(e)[:200])
+    print(f"{n_grad} autograd configurations checked")
     for kind, ctor, shape, fwd in cases:
         for mode in ("eval", "train_frozen", "train_ema"):
             x = torch.randn(*shape, generator=torch.Generator().manual_seed(11))

@@ -317,12 +317,18 @@ def test_fused_training_forward_equals_layer_by_layer(device, kind):
     fused.train()
     plain.train()
     x = torch.randn(4, 200, 32, device=device)
+    w = torch.randn(4, 200, 32, device=device)
     kw = dict(freeze_codebook=True) if kind == "rvq_shared_frozen" else {}
-    a = fused(x, **kw)
-    b = plain(x, **kw)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    a = fused(xa, **kw)
+    b = plain(xb, **kw)
     assert torch.equal(a[1], b[1])
     torch.testing.assert_close(a[0], b[0], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-6)
+    # gradients: straight-through identity per stage + commitment losses (found missing on the grouped fused path once)
+    ((a[0] * w).sum() + a[2].sum() * 2.0).backward()
+    ((b[0] * w).sum() + b[2].sum() * 2.0).backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-6)
     # (a shared codebook under EMA is searched stage by stage on both sides: the module must not fuse that case)
     for ma, mb in zip(fused.modules(), plain.modules()):
         if isinstance(ma, vq.Codebook):

@@ -141,15 +141,22 @@ class Codebook(nn.Module):
 
     # ------------------------------------------------------------------ the hot path
     def quantize_flat(self, flat: torch.Tensor, *, ste: bool = False, want_sq_err: bool = False,
-                      codebook_grad_from_err: bool = False, out=None, idx=None, want_lse: bool = False):
+                      codebook_grad_from_err: bool = False, out=None, idx=None, want_lse: bool = False,
+                      frozen: bool = False):
         """flat [h, M, D] (strided rows fine) -> (out [h, M, D], idx [h, M] int64, sq_err [1] float64 | None).
         ``want_lse``: a fourth element (lse [h, M], target_logit [h, M]) -- log-sum-exp of the row's similarities and the
-        similarity of the chosen code, from the same sweep -- or None when the sampling is stochastic."""
+        similarity of the chosen code, from the same sweep -- or None when the sampling is stochastic.
+        ``frozen``: the caller will NOT run the EMA update after this search (freeze_codebook)."""
         if self._stochastic_requested():
             res = self._quantize_stochastic(flat, ste=ste, want_sq_err=want_sq_err,
                                             codebook_grad_from_err=codebook_grad_from_err, idx=idx)
             return (*res, None) if want_lse else res
         codes = self.current_codes()
+        if (torch.is_grad_enabled() and flat.requires_grad and not codes.requires_grad and self.training and self.ema_update
+                and not frozen):
+            # the EMA step that follows rewrites the codebook in place; the backward pass (commitment loss: 2 (x - c))
+            # must see the codes this forward used, as the reference's autograd graph does (it holds `quantize` by value)
+            codes = codes.clone()
         res = search.quantize_rows(flat, codes[:, None], metric=self.metric, ste=ste, want_sq_err=want_sq_err,
                                    codebook_grad_from_err=codebook_grad_from_err, out=out, idx=idx, want_lse=want_lse)
         out, idx, sq_err = res[:3]
@@ -217,7 +224,7 @@ class Codebook(nn.Module):
             self.seed_with_kmeans(flat, flat_mask)
             self.is_initialized = True
 
-        out, idx, _ = self.quantize_flat(flat)
+        out, idx, _ = self.quantize_flat(flat, frozen=freeze_codebook)
         sims = self.similarities(flat).reshape(h, *lead, self.codebook_size) if return_similarities else None
 
         if self.training and self.ema_update and not freeze_codebook:

@@ -218,7 +218,7 @@ class VectorQuantize(nn.Module):
             # the one native launch: search + gather + straight-through + squared error
             out, idx, sq_err, *rest = cb.quantize_flat(flat, ste=training, want_sq_err=want_sq_err,
                                                        codebook_grad_from_err=cb_grad_from_err, out=out_view,
-                                                       idx=idx_view, want_lse=ce_from_search)
+                                                       idx=idx_view, want_lse=ce_from_search, frozen=freeze_codebook)
             ce_stats = rest[0] if rest else None
             if want_sq_err:
                 commit_loss = (sq_err[0] / flat.numel()).to(torch.float32)

@@ -326,7 +326,7 @@ class GroupedResidualVQ(nn.Module):
                             cbq.reseed_dead_codes(lambda g=g, q=q: residual_rows(g, q))
                         else:
                             cbq.ema_step(residual_rows(g, q), idx[g:g + 1, :, q])
-        quantized = q_buf.view(*lead, self.dim)
+        quantized = out.permute(1, 0, 2).reshape(*lead, self.dim)  # q_buf's memory; keeps the autograd edge of `out`
         all_indices = idx.reshape(G, *lead, Q)
         ret = (quantized, all_indices, losses)
         if return_all_codes:

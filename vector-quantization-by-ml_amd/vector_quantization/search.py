@@ -160,7 +160,9 @@ def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, st
         x = x.float()
     if not cb.is_contiguous():
         cb = cb.contiguous()
-    needs_grad = torch.is_grad_enabled() and (x.requires_grad or cb.requires_grad)
+    # x receives a gradient only through the straight-through output or the squared error: an eval-mode gather
+    # (out = codebook[idx]) is not differentiable with respect to x, exactly like the reference's batched_embedding
+    needs_grad = torch.is_grad_enabled() and ((x.requires_grad and (ste or want_sq_err)) or cb.requires_grad)
     if needs_grad:
         res = _QuantizeFn.apply(x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out, idx, want_lse,
                                 sq_err_per_head)
