@@ -39,6 +39,8 @@ MineParams = sys.modules["vq_dropin.params"].CodebookParams
 
 
 def compare(name, a, b, tol=1e-5):
+    if not isinstance(a, (tuple, list)) and not torch.is_tensor(a):
+        a, b = torch.as_tensor(a), torch.as_tensor(b)
     if isinstance(a, (tuple, list)):
         assert len(a) == len(b), f"{name}: {len(a)} vs {len(b)} returns"
         for i, (u, v) in enumerate(zip(a, b)):
@@ -158,6 +160,15 @@ def main():
         cases.append(("VectorQuantize", dict(base, codebook_diversity_loss_weight=0.3, codebook_diversity_temperature=2.0,
                                              cb=cbk), (2, 30, 32), {}))
         cases.append(("VectorQuantize", dict(base, cb=cbk), (2, 30, 32), dict(given_indices=True)))
+    # remaining constructor options
+    cbk = dict(dim=16, codebook_size=40, **noexp)
+    cases.append(("VectorQuantize", dict(dim=32, codebook_dim=16, layernorm_after_project_in=True, cb=cbk), (2, 30, 32), {}))
+    cases.append(("VectorQuantize", dict(dim=32, codebook_dim=16, commitment_weight=0.0, cb=cbk), (2, 30, 32), {}))
+    cases.append(("VectorQuantize", dict(dim=32, codebook_dim=16, commitment_weight=2.5, cb=cbk), (2, 30, 32),
+                  dict(return_loss_breakdown=True)))
+    cases.append(("VectorQuantize", dict(dim=32, heads=4, cb=dict(dim=32, codebook_size=40, **noexp)), (3, 32), {}))
+    cases.append(("ResidualVQ", dict(dim=32, num_quantizers=3, commitment_weight=0.25, cb=dict(dim=32, codebook_size=40, **noexp)),
+                  (2, 30, 32), {}))
     for groups in (2, 4):
         cases.append(("GroupedResidualVQ", dict(dim=32, groups=groups, num_quantizers=3,
                                                 cb=dict(dim=32 // groups, codebook_size=24, **noexp)), (2, 30, 32), {}))
