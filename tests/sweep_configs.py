@@ -1,0 +1,80 @@
+"""Configuration lists shared by the container-only reference sweep (tests/golden/sweep_against_reference.py) and the GPU
+sweep (tests/test_gpu_sweep.py): (class name, constructor kwargs with the CodebookParams kwargs under "cb", input shape,
+forward kwargs).  ``mask=True`` / ``given_indices=True`` are placeholders the runners turn into tensors."""
+from __future__ import annotations
+
+import itertools
+
+import torch
+
+
+def forward_cases():
+    cases = []
+    noexp = dict(threshold_ema_dead_code=0)
+    for heads, sep, cdim in [(1, False, None), (2, True, 16), (2, False, 16), (2, False, None)]:
+        for cos in (False, True):
+            cb = dict(dim=cdim or 32, codebook_size=40, use_cosine_sim=cos, **noexp)
+            if cos:
+                cb.update(transform_input="l2norm", weights_regularization="l2norm")
+            for shape, cl in [((2, 30, 32), True), ((2, 32, 5, 6), False), ((7, 32), True)]:
+                cases.append(("VectorQuantize", dict(dim=32, heads=heads, separate_codebook_per_head=sep, codebook_dim=cdim,
+                                                     channel_last=cl, cb=cb), shape, {}))
+    for shared, cdim, drop in itertools.product((False, True), (None, 16), (False, True)):
+        ctor = dict(dim=32, num_quantizers=4, shared_codebook=shared, codebook_dim=cdim,
+                    cb=dict(dim=cdim or 32, codebook_size=40, **noexp))
+        fwd = {}
+        if drop:
+            ctor.update(quantize_dropout=True, quantize_dropout_cutoff_index=1)
+            fwd = dict(rand_quantize_dropout_fixed_seed=3)
+        cases.append(("ResidualVQ", ctor, (2, 30, 32), fwd))
+        cases.append(("ResidualVQ", dict(ctor, cb=dict(ctor["cb"])), (2, 5, 6, 32), dict(fwd, return_all_codes=True)))
+    # masks, similarity-consuming losses, cross entropy to given indices
+    for heads, sep, cdim in [(1, False, None), (2, True, 16), (2, False, 16)]:
+        base = dict(dim=32, heads=heads, separate_codebook_per_head=sep, codebook_dim=cdim)
+        cbk = dict(dim=cdim or 32, codebook_size=40, **noexp)
+        cases.append(("VectorQuantize", dict(base, cb=cbk), (2, 30, 32), dict(mask=True)))
+        cases.append(("VectorQuantize", dict(base, commitment_use_cross_entropy_loss=True, cb=cbk), (2, 30, 32), {}))
+        cases.append(("VectorQuantize", dict(base, commitment_use_cross_entropy_loss=True, cb=cbk), (2, 30, 32), dict(mask=True)))
+        cases.append(("VectorQuantize", dict(base, codebook_diversity_loss_weight=0.3, codebook_diversity_temperature=2.0,
+                                             cb=cbk), (2, 30, 32), {}))
+        cases.append(("VectorQuantize", dict(base, cb=cbk), (2, 30, 32), dict(given_indices=True)))
+    # remaining constructor options
+    cbk = dict(dim=16, codebook_size=40, **noexp)
+    cases.append(("VectorQuantize", dict(dim=32, codebook_dim=16, layernorm_after_project_in=True, cb=cbk), (2, 30, 32), {}))
+    cases.append(("VectorQuantize", dict(dim=32, codebook_dim=16, commitment_weight=0.0, cb=cbk), (2, 30, 32), {}))
+    cases.append(("VectorQuantize", dict(dim=32, codebook_dim=16, commitment_weight=2.5, cb=cbk), (2, 30, 32),
+                  dict(return_loss_breakdown=True)))
+    cases.append(("VectorQuantize", dict(dim=32, heads=4, cb=dict(dim=32, codebook_size=40, **noexp)), (3, 32), {}))
+    cases.append(("ResidualVQ", dict(dim=32, num_quantizers=3, commitment_weight=0.25, cb=dict(dim=32, codebook_size=40, **noexp)),
+                  (2, 30, 32), {}))
+    for groups in (2, 4):
+        cases.append(("GroupedResidualVQ", dict(dim=32, groups=groups, num_quantizers=3,
+                                                cb=dict(dim=32 // groups, codebook_size=24, **noexp)), (2, 30, 32), {}))
+    return cases
+
+
+def autograd_cases():
+    learn = dict(learnable_codebook=True, ema_update=False)
+    grad_cases = [c for c in forward_cases() if "given_indices" not in c[3] and not c[1].get("quantize_dropout")][::3]
+    for cdim in (None, 16):
+        grad_cases.append(("VectorQuantize", dict(dim=32, codebook_dim=cdim, cb=dict(dim=cdim or 32, codebook_size=40, **learn)),
+                           (2, 30, 32), {}))
+        grad_cases.append(("VectorQuantize", dict(dim=32, codebook_dim=cdim, sync_update_v=0.3,
+                                                  cb=dict(dim=cdim or 32, codebook_size=40, **learn)), (2, 30, 32), {}))
+        grad_cases.append(("ResidualVQ", dict(dim=32, num_quantizers=3, codebook_dim=cdim,
+                                              cb=dict(dim=cdim or 32, codebook_size=40, **learn)), (2, 30, 32), {}))
+    return grad_cases
+
+
+def materialise_forward_kwargs(ctor, cb_kw, x, fwd):
+    """Turn the placeholders into tensors (same seeds on every side of a comparison)."""
+    kw = dict(fwd)
+    if "mask" in kw:
+        kw["mask"] = torch.arange(x.shape[1])[None, :] < torch.tensor([x.shape[1], max(1, x.shape[1] // 2)])[:, None]
+    if kw.pop("given_indices", False):
+        heads = ctor.get("heads", 1)
+        n = (x.numel() // (x.shape[0] * x.shape[-1]) if ctor.get("channel_last", True)
+             else x.numel() // (x.shape[0] * x.shape[1]))
+        kw["indices"] = torch.randint(0, cb_kw["codebook_size"], (x.shape[0], n, heads) if heads > 1 else (x.shape[0], n),
+                                      generator=torch.Generator().manual_seed(3))
+    return kw
