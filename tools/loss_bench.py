@@ -1,4 +1,5 @@
-"""Timing of the similarity-consuming entry points at the cfg2 shape (diagnostic; not the bench of record).
+"""Timings beyond the bench of record: similarity-consuming entry points, training-mode forwards / full steps at cfg2 and
+cfg4, cfg1 latency with and without hipGraph replay (diagnostic; DESIGN.md quotes these).
 
     python tools/loss_bench.py            # on the GPU box
 """
@@ -141,11 +142,6 @@ def rvq_train():
     print(f"ResidualVQ cfg4: eval forward {t_eval:.2f} ms, train forward with EMA {t_train:.2f} ms, forward + backward {t_step:.2f} ms")
 
 
-if __name__ == "__main__":
-    main()
-    train_steps()
-    train_backward()
-    rvq_train()
 
 
 def cfg1_latency():
@@ -166,4 +162,8 @@ def cfg1_latency():
 
 
 if __name__ == "__main__":
+    main()
+    train_steps()
+    train_backward()
+    rvq_train()
     cfg1_latency()
