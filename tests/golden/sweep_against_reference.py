@@ -157,5 +157,55 @@ def main():
     print(f"{len(cases) * 3} configurations, {n_bad} deviations")
 
 
+def accessor_sweep():
+    """codebooks / get_codes_from_indices / get_output_from_indices of the three module families (several are broken in the
+    fork -- ``_codebook.embed`` does not exist -- and are repaired in the drop-in: reported, not counted as deviations)."""
+    def pair(kind, cb_kw, **ctor):
+        torch.manual_seed(7)
+        r = getattr(ref, kind)(codebook_params=ref_cb.CodebookParams(**cb_kw), **ctor)
+        m = getattr(mine, kind)(codebook_params=MineParams(**cb_kw), **ctor)
+        m.load_state_dict(r.state_dict()); r.eval(); m.eval()
+        return r, m
+    def check(name, fr, fm):
+        try:
+            a = fr()
+        except Exception as e:
+            try:
+                fm(); print(name, "ref raises", type(e).__name__, "| mine works (repaired)")
+            except Exception as e2:
+                print(name, "both raise", type(e).__name__, type(e2).__name__)
+            return
+        b = fm()
+        try:
+            compare(name, b, a); print(name, "AGREE")
+        except AssertionError as e:
+            print(name, "DEVIATION", e)
+    x = torch.randn(2, 20, 32)
+    for cdim in (None, 16):
+        r, m = pair("ResidualVQ", dict(dim=cdim or 32, codebook_size=24), dim=32, num_quantizers=3, codebook_dim=cdim)
+        with torch.no_grad():
+            _, idx, _ = r(x)
+        check(f"rvq.codebooks cdim={cdim}", lambda: r.codebooks, lambda: m.codebooks)
+        check(f"rvq.get_codes_from_indices cdim={cdim}", lambda: r.get_codes_from_indices(idx), lambda: m.get_codes_from_indices(idx))
+        check(f"rvq.get_output_from_indices cdim={cdim}", lambda: r.get_output_from_indices(idx), lambda: m.get_output_from_indices(idx))
+        idx2 = idx.clone(); idx2[..., 2] = -1
+        check(f"rvq.get_codes_from_indices dropped cdim={cdim}", lambda: r.get_codes_from_indices(idx2), lambda: m.get_codes_from_indices(idx2))
+        check(f"rvq.get_codes_from_indices short cdim={cdim}", lambda: r.get_codes_from_indices(idx[..., :2]), lambda: m.get_codes_from_indices(idx[..., :2]))
+    r, m = pair("GroupedResidualVQ", dict(dim=16, codebook_size=24), dim=32, groups=2, num_quantizers=3)
+    with torch.no_grad():
+        _, gidx, _ = r(x)
+    check("grvq.codebooks", lambda: r.codebooks, lambda: m.codebooks)
+    check("grvq.get_codes_from_indices", lambda: r.get_codes_from_indices(gidx), lambda: m.get_codes_from_indices(gidx))
+    check("grvq.get_output_from_indices", lambda: r.get_output_from_indices(gidx), lambda: m.get_output_from_indices(gidx))
+    for heads, sep in ((1, False), (2, True)):
+        r, m = pair("VectorQuantize", dict(dim=32 // heads, codebook_size=24), dim=32, heads=heads, codebook_dim=32 // heads, separate_codebook_per_head=sep)
+        with torch.no_grad():
+            _, vidx, _ = r(x)
+        check(f"vq.codebook heads={heads}", lambda: r.codebook, lambda: m.codebook)
+        check(f"vq.get_codes_from_indices heads={heads}", lambda: r.get_codes_from_indices(vidx), lambda: m.get_codes_from_indices(vidx))
+        check(f"vq.get_output_from_indices heads={heads}", lambda: r.get_output_from_indices(vidx), lambda: m.get_output_from_indices(vidx))
+
+
 if __name__ == "__main__":
     main()
+    accessor_sweep()
