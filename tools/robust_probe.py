@@ -67,3 +67,43 @@ check_aux(48, 100, 1000, 16)           # many heads
 check_aux(3, 20_000, 5000, 200, metric=1)
 check_aux(2, 5_000, 300, 384)          # D padded to 512
 check_aux(1, 129, 33, 250)             # D padded to 256, one partial block
+
+
+def check_train(H, M, K, D, Q=1):
+    """training-side kernels at awkward sizes: quantize backward and the EMA statistics vs float64 torch on sampled rows."""
+    g = torch.Generator().manual_seed(H * 13 + K + Q)
+    x = torch.randn((H, M, D), generator=g).to(dev)
+    cb = (torch.randn((H, Q, K, D), generator=g) * 0.7).to(dev)
+    r = native.quantize(x, cb, ste=True, want_sq_err=True, idx=torch.empty((H, M, Q), dtype=torch.int64, device=dev))
+    idx = r["idx"]
+    go = torch.randn((H, M, D), generator=g).to(dev)
+    ge = torch.rand((Q,), generator=g, dtype=torch.float64).to(dev)
+    gx = native.quantize_backward(x, cb, idx, go, ge, ste=True)
+    counts, sums = native.ema_accumulate_residual(x, cb, idx, ste=True)
+    c1, s1 = native.ema_accumulate(x, idx[..., 0].contiguous(), K)
+    torch.cuda.synchronize()
+    ok = True
+    rows = torch.cat([torch.randperm(M, generator=g)[:512], torch.tensor([0, M - 1])]).to(dev)
+    for h in range(min(H, 2)):
+        res = x[h, rows].double()
+        want = go[h, rows].double() * Q
+        for q in range(Q):
+            c = cb[h, q][idx[h, rows, q]].double()
+            want = want + 2.0 * ge[q] * (res - c)
+            res = res - (res + (c - res))
+        ok &= bool((gx[h, rows].double() - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max())))
+        # stage-0 statistics: both kernels against index_add over ALL rows
+        ws = torch.zeros((K, D), dtype=torch.float64, device=dev).index_add_(0, idx[h, :, 0], x[h].double())
+        wc = torch.bincount(idx[h, :, 0], minlength=K).double()
+        for cc, ss in ((counts[h, 0], sums[h, 0]), (c1[h], s1[h])):
+            ok &= bool(torch.equal(cc.double(), wc))
+            ok &= bool((ss.double() - ws).abs().max() <= 1e-4 * max(1.0, float(ws.abs().max())))
+    print(f"train H={H} M={M} K={K} D={D} Q={Q}: {'OK' if ok else 'MISMATCH'}")
+    torch.cuda.empty_cache()
+
+
+check_train(1, 2_000_003, 64, 64)          # owner-computes EMA kernel, > 2^31 bytes nowhere, odd M
+check_train(1, 300_000, 1000, 200)         # padded D (unaligned rows), many owners
+check_train(6, 50_000, 128, 32, Q=3)       # heads x stages
+check_train(1, 9_000, 4096, 512, Q=2)      # Dp = 512 residual
+check_train(2, 70_001, 33, 100)            # tiny K
