@@ -67,6 +67,45 @@ class OracleBackend:
 
 
     @staticmethod
+    def ema_accumulate(x, idx, k, mask=None):
+        """counts / sums of the rows assigned to each code, with plain index arithmetic (reference: one-hot products)."""
+        h, m, d = x.shape
+        weights = torch.ones((h, m), dtype=x.dtype)
+        if mask is not None:
+            weights = weights * mask.to(x.dtype)
+        hits = torch.zeros((h, k), dtype=x.dtype).scatter_add_(1, idx, weights)
+        sums = torch.zeros((h, k, d), dtype=x.dtype).scatter_add_(1, idx[..., None].expand(h, m, d), x * weights[..., None])
+        return hits, sums
+
+    @staticmethod
+    def ema_accumulate_residual(x, cb, idx, *, ste, share):
+        h, m, d = x.shape
+        q_stages, k = idx.shape[-1], cb.shape[2]
+        hits = torch.zeros((h, q_stages, k), dtype=x.dtype)
+        sums = torch.zeros((h, q_stages, k, d), dtype=x.dtype)
+        r = x
+        harange = torch.arange(h)[:, None]
+        for q in range(q_stages):
+            hits[:, q], sums[:, q] = OracleBackend.ema_accumulate(r, idx[..., q], k)
+            c = cb[:, 0 if share else q][harange, idx[..., q]]
+            quant = r + (c - r) if ste else c
+            r = r - quant
+        return hits, sums
+
+    @staticmethod
+    def ema_update(cluster_size, embed_avg, embeddings, hits, sums, *, decay, eps, l2norm):
+        """codebooks.py:411,417-425 with the reference's own tensor ops."""
+        k = cluster_size.shape[-1]
+        cluster_size.lerp_(hits, 1.0 - decay)
+        embed_avg.lerp_(sums, 1.0 - decay)
+        total = cluster_size.sum(dim=-1, keepdim=True)
+        smoothed = (cluster_size + eps) / (total + k * eps) * total
+        fresh = embed_avg / smoothed[..., None]
+        if l2norm:
+            fresh = torch.nn.functional.normalize(fresh, p=2, dim=-1)
+        embeddings.copy_(fresh)
+
+    @staticmethod
     def similarities(x, cb, *, metric, out=None):
         xn = np.ascontiguousarray(x.detach().cpu().numpy(), dtype=np.float32)
         cbn = np.ascontiguousarray(cb.detach().cpu().numpy(), dtype=np.float32)

@@ -271,6 +271,9 @@ class _TorchBackwardBackend:
         self.quantize = native_backend.quantize
         self.similarities = native_backend.similarities
         self.softmax_stats = native_backend.softmax_stats
+        self.ema_accumulate = native_backend.ema_accumulate
+        self.ema_accumulate_residual = native_backend.ema_accumulate_residual
+        self.ema_update = native_backend.ema_update
 
 
 @pytest.mark.parametrize("kind", ["vq", "vq_eval_learnable_off", "vq_heads_sep", "vq_heads_shared", "rvq", "rvq_shared", "grvq"])

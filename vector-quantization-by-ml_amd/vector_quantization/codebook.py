@@ -241,45 +241,20 @@ class Codebook(nn.Module):
     def ema_step(self, flat: torch.Tensor, idx: torch.Tensor, flat_mask=None):
         """Exponential-moving-average codebook update + dead-code re-seeding (codebooks.py:399-426),
         expressed with index arithmetic instead of the reference's [h, M, K] one-hot products."""
-        h, m, d = flat.shape
-        k = self.codebook_size
-        if flat.is_cuda:
-            # native: scatter-add with float atomics, then one fused lerp / smoothing / normalise pass
-            from . import native
-
-            hits, sums = native.ema_accumulate(flat, idx, k, flat_mask)
-            self.ema_apply(hits, sums)
-        else:  # host tensors only occur under the tests' checker backend
-            weights = torch.ones((h, m), dtype=flat.dtype, device=flat.device)
-            if flat_mask is not None:
-                weights = weights * flat_mask.to(flat.dtype)
-            hits = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
-            hits.scatter_add_(1, idx, weights)
-            self._sync_sum(hits)
-            self.cluster_size.data.lerp_(hits, 1.0 - self.decay)
-
-            sums = torch.zeros((h, k, d), dtype=flat.dtype, device=flat.device)
-            sums.scatter_add_(1, idx[..., None].expand(h, m, d), flat * weights[..., None])
-            self._sync_sum(sums)
-            self.embed_avg.data.lerp_(sums, 1.0 - self.decay)
-
-            total = self.cluster_size.sum(dim=-1, keepdim=True)
-            smoothed = (self.cluster_size + self.eps_for_smoothing) / (total + k * self.eps_for_smoothing) * total
-            fresh = self.weights_regularization(self.embed_avg / smoothed[..., None])
-            self.embeddings.data.copy_(fresh)
+        hits, sums = search.get_backend().ema_accumulate(flat, idx, self.codebook_size, flat_mask)
+        self.ema_apply(hits, sums)
         self.reseed_dead_codes(flat)
 
     @torch.no_grad()
     def ema_apply(self, hits: torch.Tensor, sums: torch.Tensor):
-        """Second half of the EMA step from ready statistics (hits [h, K], sums [h, K, D], contiguous, on the GPU):
-        replica sync, lerp, Laplace smoothing, normalise -- codebooks.py:410-425."""
-        from . import native
-
+        """Second half of the EMA step from ready statistics (hits [h, K], sums [h, K, D]): replica sync, lerp, Laplace
+        smoothing, normalise -- codebooks.py:410-425."""
         hits, sums = hits.contiguous(), sums.contiguous()
         self._sync_sum(hits)
         self._sync_sum(sums)
-        native.ema_update(self.cluster_size.data, self.embed_avg.data, self.embeddings.data, hits, sums, self.decay,
-                          self.eps_for_smoothing, self.weights_regularization is _unit_rows)
+        search.get_backend().ema_update(self.cluster_size.data, self.embed_avg.data, self.embeddings.data, hits, sums,
+                                        decay=self.decay, eps=self.eps_for_smoothing,
+                                        l2norm=self.weights_regularization is _unit_rows)
 
     @torch.no_grad()
     def reseed_dead_codes(self, flat):
@@ -317,15 +292,7 @@ class Codebook(nn.Module):
         counts = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
         for _ in range(iters):
             idx, _best, _ = search.nearest_with_distance(data, means, metric=self.metric)
-            if data.is_cuda:
-                from . import native
-
-                counts, sums = native.ema_accumulate(data.contiguous(), idx.contiguous(), k)
-            else:  # host tensors only occur under the tests' checker backend
-                counts = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
-                counts.scatter_add_(1, idx, torch.ones((h, m), dtype=flat.dtype, device=flat.device))
-                sums = torch.zeros((h, k, d), dtype=flat.dtype, device=flat.device)
-                sums.scatter_add_(1, idx[..., None].expand(h, m, d), data)
+            counts, sums = search.get_backend().ema_accumulate(data.contiguous(), idx.contiguous(), k)
             if sync and dist.is_initialized():
                 dist.all_reduce(counts)
                 dist.all_reduce(sums)

@@ -172,22 +172,16 @@ class ResidualVQ(nn.Module):
                 chain = []
 
                 def residual_rows(q):
-                    if not chain:  # only needed when a code expired, or on host tensors (tests' checker backend)
+                    if not chain:  # only needed when a code expired
                         chain.extend(_residual_chain(flat[0].detach(), stage_codes.detach(), idx[0], ste=True))
                     return chain[q][None]
 
-                if flat.is_cuda:
-                    # one native pass rebuilds the residual chain from the indices and scatter-adds every stage's statistics
-                    from . import native
-
-                    hits, sums = native.ema_accumulate_residual(flat.detach(), codes.detach().contiguous(), idx, ste=True,
-                                                                stages_share_codebook=self.shared_codebook)
-                    for q, layer in enumerate(self.layers):
-                        layer._codebook.ema_apply(hits[:, q], sums[:, q])
-                        layer._codebook.reseed_dead_codes(lambda q=q: residual_rows(q))
-                else:
-                    for q, layer in enumerate(self.layers):
-                        layer._codebook.ema_step(residual_rows(q), idx[:, :, q])
+                # one pass rebuilds the residual chain from the indices and scatter-adds every stage's statistics
+                hits, sums = search.get_backend().ema_accumulate_residual(flat.detach(), codes.detach().contiguous(), idx,
+                                                                          ste=True, share=self.shared_codebook)
+                for q, layer in enumerate(self.layers):
+                    layer._codebook.ema_apply(hits[:, q], sums[:, q])
+                    layer._codebook.reseed_dead_codes(lambda q=q: residual_rows(q))
         return out.reshape(*lead, d), idx.reshape(*lead, Q), losses
 
     def _forward_layers(self, x, mask, freeze_codebook, drop_active, fixed_seed):
@@ -308,24 +302,18 @@ class GroupedResidualVQ(nn.Module):
                 chains = {}
 
                 def residual_rows(g, q):
-                    if g not in chains:  # only when a code expired, or on host tensors (tests' checker backend)
+                    if g not in chains:  # only when a code expired
                         chains[g] = _residual_chain(flat[g].detach(), codes[g].detach(), idx[g], ste=True)
                     return chains[g][q][None]
 
-                if flat.is_cuda:
-                    from . import native
-
-                    hits, sums = native.ema_accumulate_residual(flat.detach(), codes.detach().contiguous(), idx, ste=True)
+                hits, sums = search.get_backend().ema_accumulate_residual(flat.detach(), codes.detach().contiguous(), idx,
+                                                                          ste=True, share=False)
                 for g, rvq in enumerate(self.rvqs):
                     for q, layer in enumerate(rvq.layers):
                         cbq = layer._codebook
-                        if not cbq.ema_update:
-                            continue
-                        if flat.is_cuda:
+                        if cbq.ema_update:
                             cbq.ema_apply(hits[g:g + 1, q], sums[g:g + 1, q])
                             cbq.reseed_dead_codes(lambda g=g, q=q: residual_rows(g, q))
-                        else:
-                            cbq.ema_step(residual_rows(g, q), idx[g:g + 1, :, q])
         quantized = out.permute(1, 0, 2).reshape(*lead, self.dim)  # q_buf's memory; keeps the autograd edge of `out`
         all_indices = idx.reshape(G, *lead, Q)
         ret = (quantized, all_indices, losses)

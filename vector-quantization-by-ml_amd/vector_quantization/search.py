@@ -1,8 +1,9 @@
 """Functional seam between the nn.Modules and the native op.
 
 ``quantize_rows`` is the ONE call every module makes for the hot path.  It dispatches to
-``native.quantize`` (HIP kernels through the C ABI).  There is no CPU implementation in this package;
-tests may install a checker backend with ``set_backend`` (tests/ only) to exercise the host-side
+``native.quantize`` (HIP kernels through the C ABI).  There is no CPU implementation in this package -- not for the
+search, not for the similarity consumers, not for the EMA statistics: every device-side step goes through the backend
+object below.  Tests may install a checker backend with ``set_backend`` (tests/ only) to exercise the host-side
 layout logic on a machine without a GPU.
 """
 from __future__ import annotations
@@ -42,6 +43,21 @@ class _NativeBackend:
         """-> (logsumexp_k scale * sim [H, M], logit of target [H, M] | None)  (vq_softmax_stats_f32)."""
         return native.softmax_stats(x, cb.contiguous(), metric=metric, scale=scale, target=target)
 
+
+    @staticmethod
+    def ema_accumulate(x, idx, k, mask=None):
+        """-> (counts [H, K], sums [H, K, D]) of the rows assigned to each code (vq_ema_accumulate_f32)."""
+        return native.ema_accumulate(x, idx, k, mask)
+
+    @staticmethod
+    def ema_accumulate_residual(x, cb, idx, *, ste, share):
+        """-> (counts [H, Q, K], sums [H, Q, K, D]) for every stage of a residual stack (vq_ema_accumulate_residual_f32)."""
+        return native.ema_accumulate_residual(x, cb, idx, ste=ste, stages_share_codebook=share)
+
+    @staticmethod
+    def ema_update(cluster_size, embed_avg, embeddings, hits, sums, *, decay, eps, l2norm):
+        """In-place lerp / Laplace smoothing / normalise of the module buffers (vq_ema_update_f32)."""
+        native.ema_update(cluster_size, embed_avg, embeddings, hits, sums, decay, eps, l2norm)
 
     @staticmethod
     def quantize_backward(x, cb, idx, grad_out, grad_sq_err, *, ste, share, sq_err_per_head=False):
