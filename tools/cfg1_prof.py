@@ -1,5 +1,10 @@
-import sys, os
-sys.path[:0] = ["/root/repo", "/root/repo/vector-quantization-by-ml_amd"]
+"""Eager cfg1 forwards for `rocprofv3 --kernel-trace --stats -- python3 tools/cfg1_prof.py` (per-kernel durations at the
+reference's CPU-sized configuration)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vector-quantization-by-ml_amd")]
 import torch
 import vector_quantization as vq
 from vector_quantization.codebooks import CodebookParams
