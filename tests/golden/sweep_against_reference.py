@@ -206,6 +206,46 @@ def accessor_sweep():
         check(f"vq.get_output_from_indices heads={heads}", lambda: r.get_output_from_indices(vidx), lambda: m.get_output_from_indices(vidx))
 
 
+
+
+def dtype_sweep():
+    """Half / bfloat16 / double inputs: values AND output dtypes (the reference computes in fp32 but its straight-through
+    sum promotes to the input's width in train mode)."""
+    for dt in (torch.float16, torch.bfloat16, torch.float64):
+        for kind, ctor in (("VectorQuantize", dict(dim=32)), ("VectorQuantize", dict(dim=32, heads=2, codebook_dim=16, separate_codebook_per_head=True)), ("ResidualVQ", dict(dim=32, num_quantizers=3)),
+                               ("GroupedResidualVQ", dict(dim=32, groups=2, num_quantizers=2))):
+            for mode in ("eval", "train"):
+                torch.manual_seed(7)
+                cbk = dict(dim=ctor.get("codebook_dim") or (16 if kind == "GroupedResidualVQ" else 32), codebook_size=40,
+                           threshold_ema_dead_code=0)
+                r = getattr(ref, kind)(codebook_params=ref_cb.CodebookParams(**cbk), **ctor)
+                m = getattr(mine, kind)(codebook_params=MineParams(**cbk), **ctor)
+                m.load_state_dict(r.state_dict())
+                x = torch.randn(2, 30, 32, generator=torch.Generator().manual_seed(11)).to(dt)
+                for mod in (r, m):
+                    mod.train() if mode == "train" else mod.eval()
+                try:
+                    with torch.no_grad():
+                        a = r(x)
+                except Exception as e:
+                    try:
+                        with torch.no_grad(): m(x)
+                        print(dt, kind, mode, "ref raises", type(e).__name__, str(e)[:60], "| mine works")
+                    except Exception as e2:
+                        print(dt, kind, mode, "both raise", type(e).__name__, type(e2).__name__)
+                    continue
+                with torch.no_grad():
+                    b = m(x)
+                msg = []
+                for i, (u, v) in enumerate(zip(a, b)):
+                    if u.dtype != v.dtype: msg.append(f"out[{i}] dtype {u.dtype} vs {v.dtype}")
+                    elif u.dtype == torch.int64:
+                        if not torch.equal(u, v): msg.append(f"out[{i}] {int((u!=v).sum())} idx differ")
+                    elif float((u.double()-v.double()).abs().max()) > 1e-3: msg.append(f"out[{i}] err {float((u.double()-v.double()).abs().max())}")
+                print(dt, kind, ctor.get("heads",1), mode, "AGREE" if not msg else "DEVIATION " + "; ".join(msg))
+
+
 if __name__ == "__main__":
     main()
     accessor_sweep()
+    dtype_sweep()

@@ -161,6 +161,7 @@ class VectorQuantize(nn.Module):
         head_dim = x.shape[-1] // heads
         x4 = x.reshape(batch, n, heads, head_dim)
         x4 = cb.transform_input(x4)
+        wide_input = x4.dtype == torch.float64  # the reference's straight-through sum x + (q - x) promotes to the input's width
         if x4.dtype != torch.float32:
             x4 = x4.float()
         if not x4.is_contiguous():
@@ -231,6 +232,8 @@ class VectorQuantize(nn.Module):
                 commit_loss = ((target - flat) ** 2)[flat_mask].mean()
             if training:
                 out = flat + (out - flat).detach()
+        if training and wide_input:
+            out = out.double()
         if training and self.sync_update_v > 0.0:
             # eq. (21) of the vqtorch draft (vector_quantize_pytorch.py:275-279): same value, gradient scaled by 1 + v
             out = out + self.sync_update_v * (out - out.detach())

@@ -151,6 +151,7 @@ class ResidualVQ(nn.Module):
         training = self.training
         lead, d = x.shape[:-1], x.shape[-1]
         flat = x.reshape(1, x.numel() // max(d, 1), d)
+        wide_input = flat.dtype == torch.float64  # train mode: the reference's straight-through sums are in the input's width
         if flat.dtype != torch.float32:
             flat = flat.float()
         Q = self.num_quantizers
@@ -182,6 +183,8 @@ class ResidualVQ(nn.Module):
                 for q, layer in enumerate(self.layers):
                     layer._codebook.ema_apply(hits[:, q], sums[:, q])
                     layer._codebook.reseed_dead_codes(lambda q=q: residual_rows(q))
+        if training and wide_input:
+            out = out.double()
         return out.reshape(*lead, d), idx.reshape(*lead, Q), losses
 
     def _forward_layers(self, x, mask, freeze_codebook, drop_active, fixed_seed):
@@ -315,6 +318,8 @@ class GroupedResidualVQ(nn.Module):
                             cbq.ema_apply(hits[g:g + 1, q], sums[g:g + 1, q])
                             cbq.reseed_dead_codes(lambda g=g, q=q: residual_rows(g, q))
         quantized = out.permute(1, 0, 2).reshape(*lead, self.dim)  # q_buf's memory; keeps the autograd edge of `out`
+        if training and x.dtype == torch.float64:
+            quantized = quantized.double()
         all_indices = idx.reshape(G, *lead, Q)
         ret = (quantized, all_indices, losses)
         if return_all_codes:
