@@ -50,6 +50,17 @@ def forward_cases():
     for groups in (2, 4):
         cases.append(("GroupedResidualVQ", dict(dim=32, groups=groups, num_quantizers=3,
                                                 cb=dict(dim=32 // groups, codebook_size=24, **noexp)), (2, 30, 32), {}))
+    # masks on the stacks, learnable codebook with a mask, EMA parameter variations
+    cases.append(("ResidualVQ", dict(dim=32, num_quantizers=3, cb=dict(dim=32, codebook_size=40, **noexp)), (2, 30, 32), dict(mask=True)))
+    cases.append(("ResidualVQ", dict(dim=32, num_quantizers=3, shared_codebook=True, cb=dict(dim=32, codebook_size=40, **noexp)),
+                  (2, 30, 32), dict(mask=True)))
+    cases.append(("GroupedResidualVQ", dict(dim=32, groups=2, num_quantizers=2, cb=dict(dim=16, codebook_size=24, **noexp)),
+                  (2, 30, 32), dict(mask=True)))
+    cases.append(("VectorQuantize", dict(dim=32, cb=dict(dim=32, codebook_size=40, learnable_codebook=True, ema_update=False, **noexp)),
+                  (2, 30, 32), dict(mask=True)))
+    cases.append(("VectorQuantize", dict(dim=32, cb=dict(dim=32, codebook_size=40, decay=0.5, eps_for_smoothing=1e-3, **noexp)),
+                  (2, 30, 32), {}))
+    cases.append(("VectorQuantize", dict(dim=32, cb=dict(dim=32, codebook_size=40, ema_update=False, **noexp)), (2, 30, 32), {}))
     return cases
 
 
