@@ -58,6 +58,39 @@ def _pick_rows(rows: torch.Tensor, count: int) -> torch.Tensor:
     return rows[sel]
 
 
+def _pick_rows_all_ranks(rows: torch.Tensor, count: int) -> torch.Tensor:
+    """`count` rows drawn from the union of every rank's rows, IDENTICAL on all ranks (utils/distributed.py:56-78): rank 0
+    splits `count` over the ranks in proportion to their row counts (sequential binomial draws), every rank samples its share
+    locally, the shares are exchanged.  Replicas that seed or re-seed codes from this keep bit-identical codebooks."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [torch.zeros((), dtype=torch.long, device=rows.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor(rows.shape[0], dtype=torch.long, device=rows.device))
+    sizes = torch.stack(sizes)
+    if rank == 0:
+        probs = (sizes / sizes.sum()).cpu()
+        left = probs.new_full((), count)
+        remainder = probs.new_ones(())
+        share = torch.empty_like(probs, dtype=torch.long)
+        for i, p in enumerate(probs):
+            drawn = torch.binomial(left, p / remainder)
+            share[i] = drawn
+            left -= drawn
+            remainder -= p
+        assert left == 0, f"invalid total count {left}"
+        share = share.to(rows.device)
+    else:
+        share = torch.empty_like(sizes)
+    dist.broadcast(share, src=0)
+    share = share.tolist()
+    mine = _pick_rows(rows, share[rank])
+    parts = []
+    for src, n in enumerate(share):
+        part = mine if src == rank else rows.new_empty((n, *rows.shape[1:]))
+        dist.broadcast(part, src=src)
+        parts.append(part)
+    return torch.cat(parts, dim=0)
+
+
 class Codebook(nn.Module):
     def __init__(
         self,
@@ -271,7 +304,15 @@ class Codebook(nn.Module):
             n_dead = int(dead[head].sum().item())
             if n_dead == 0:
                 continue
-            picked = _pick_rows(pool[head], n_dead)
+            kmeans_sync = (self.kmeans_params or {}).get("sync", True)
+            spread = self.use_ddp and dist.is_available() and dist.is_initialized()
+            if spread and kmeans_sync and self.distributed_replace_codes:
+                picked = _pick_rows_all_ranks(pool[head], n_dead)  # the same replacement vectors on every replica
+            else:
+                picked = _pick_rows(pool[head], n_dead)
+                if spread and not self.distributed_replace_codes:  # codebooks.py:236-237: average the replicas' draws
+                    dist.all_reduce(picked)
+                    picked = picked / dist.get_world_size()
             self.embeddings.data[head][dead[head]] = picked
             self.cluster_size.data[head][dead[head]] = self.reset_cluster_size
             self.embed_avg.data[head][dead[head]] = picked * self.reset_cluster_size
@@ -288,7 +329,8 @@ class Codebook(nn.Module):
         iters = (self.kmeans_params or {}).get("iter", 10)
         sync = self.use_ddp and (self.kmeans_params or {}).get("sync", True)
         data = _unit_rows(flat) if self.use_cosine_sim else flat
-        means = torch.stack([_pick_rows(data[i], k) for i in range(h)])
+        pick = _pick_rows_all_ranks if (sync and dist.is_available() and dist.is_initialized()) else _pick_rows
+        means = torch.stack([pick(data[i], k) for i in range(h)])
         counts = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)
         for _ in range(iters):
             idx, _best, _ = search.nearest_with_distance(data, means, metric=self.metric)
