@@ -245,7 +245,44 @@ def dtype_sweep():
                 print(dt, kind, ctor.get("heads",1), mode, "AGREE" if not msg else "DEVIATION " + "; ".join(msg))
 
 
+def codebook_sweep():
+    """Codebook.forward called directly (the internal seam, codebooks.py:351-435): three returns incl. the similarities."""
+    MineCb = sys.modules["vq_dropin.codebook"].Codebook
+    bad=0
+    for h in (1, 3):
+        for cos in (False, True):
+            for shape in ((2, 20, 16), (h, 2, 20, 16)):
+                if len(shape)==3 and h>1: continue
+                for mode in ("eval","train"):
+                    for use_mask in (False, True):
+                        torch.manual_seed(3)
+                        kw=dict(dim=16, codebook_size=24, num_codebooks=h, threshold_ema_dead_code=0, use_cosine_sim=cos)
+                        r=ref_cb.Codebook(**kw); m=MineCb(**kw); m.load_state_dict(r.state_dict())
+                        getattr(r,mode)(); getattr(m,mode)()
+                        x=torch.randn(*shape, generator=torch.Generator().manual_seed(1))
+                        mask=None
+                        if use_mask:
+                            b,n=shape[-3],shape[-2]
+                            mask=torch.arange(n)[None,:] < torch.tensor([n, n//2])[:,None]
+                        try:
+                            with torch.no_grad(): a=r(x, mask=mask)
+                        except Exception as e:
+                            try:
+                                with torch.no_grad(): m(x, mask=mask)
+                                print("ref raises", type(e).__name__, str(e)[:80], "| mine works", h,cos,shape,mode,use_mask)
+                            except Exception as e2: pass
+                            continue
+                        with torch.no_grad(): b_=m(x, mask=mask)
+                        try:
+                            compare("codebook out", b_, a)
+                            for k,v in r.state_dict().items(): compare(f"state[{k}]", m.state_dict()[k], v, tol=1e-4)
+                        except AssertionError as e:
+                            bad+=1; print("DEVIATION", h,cos,shape,mode,use_mask, e)
+    print("deviations", bad)
+
+
 if __name__ == "__main__":
     main()
     accessor_sweep()
     dtype_sweep()
+    codebook_sweep()

@@ -239,8 +239,10 @@ class Codebook(nn.Module):
 
         return losses.similarity_matrix(flat, self.current_codes(), self.metric)
 
-    def forward(self, x, mask=None, freeze_codebook=False, return_similarities=False):
-        """(quantize, embed_ind, similarities) like the reference; ``similarities`` is None unless asked for."""
+    def forward(self, x, mask=None, freeze_codebook=False, return_similarities=True):
+        """(quantize, embed_ind, similarities) like the reference (codebooks.py:351,435).  A direct caller gets the full
+        ``[h, ..., K]`` similarity tensor, as the reference returns it; pass ``return_similarities=False`` to skip its
+        materialisation (the modules of this package never call this method: they use ``quantize_flat``)."""
         squeeze_head = x.ndim < 4
         x = x.float()
         if squeeze_head:
