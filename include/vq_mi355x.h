@@ -37,6 +37,8 @@ extern "C" {
 #define VQ_F_STE 1u          /* out = x + (q - x)  (train-mode straight-through, vector_quantize_pytorch.py:273) */
 #define VQ_F_FORCE_SIMPLE 2u /* use the scalar-FMA fallback kernel instead of the MFMA kernel (cross-check)        */
 #define VQ_F_FORCE_SPLIT 4u  /* force the split-K + packed-key path even when the fused path would be chosen        */
+#define VQ_F_X_F16 16u        /* a->x points to fp16 rows (strides in elements); inference only: no STE / sq_err          */
+#define VQ_F_X_BF16 32u       /* a->x points to bf16 rows; both are widened in the prologue = the reference's x.float() */
 #define VQ_F_SQERR_PER_HEAD 8u /* sq_err (and grad_sq_err of the backward) are [H][Q]: one sum per head and stage     */
 
 /*

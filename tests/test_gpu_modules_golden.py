@@ -224,10 +224,10 @@ def test_similarities_on_demand_and_codebook_forward_api():
     dev = "cuda:0"
     cb = Codebook(dim=16, codebook_size=32, num_codebooks=2).to(dev).eval()
     x = torch.randn(2, 3, 11, 16, device=dev)  # [h, b, n, d]
-    q, ind, sims = cb(x, return_similarities=True)
+    q, ind, sims = cb(x)  # like the reference: the third return value is the full similarity tensor
     assert q.shape == x.shape and ind.shape == (2, 3, 11) and sims.shape == (2, 3, 11, 32)
     assert torch.equal(ind, sims.argmax(-1))
-    q2, ind2, none = cb(x)
+    q2, ind2, none = cb(x, return_similarities=False)
     assert none is None and torch.equal(ind2, ind) and torch.equal(q2, q)
     x3 = torch.randn(3, 11, 16, device=dev)  # [b, n, d] with a single codebook
     cb1 = Codebook(dim=16, codebook_size=32).to(dev).eval()

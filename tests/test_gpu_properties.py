@@ -330,3 +330,42 @@ def test_graphed_forward_replays_on_new_data_and_new_weights(oracle, kind):
         fast(torch.randn(8, 256, 64, device=DEV))
     with pytest.raises(ValueError):
         vq.GraphedForward(mod.train(), torch.randn(32, 256, 64, device=DEV))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,M,K,D", [(1, 4096, 1024, 256), (3, 500, 300, 100), (1, 64, 4096, 512), (2, 1000, 96, 30)])
+def test_two_byte_rows_are_widened_in_the_kernel(dtype, H, M, K, D):
+    """fp16 / bf16 rows (inference): the kernel's prologue widens them -- the reference's x.float() -- so indices,
+    distances and quantized rows are bit-identical to the launch on the pre-widened tensor."""
+    from vector_quantization import native
+
+    g = torch.Generator().manual_seed(K + D)
+    x = torch.randn((H, M, D), generator=g).to(dtype).cuda()
+    cb = torch.randn((H, 1, K, D), generator=g).cuda()
+    a = native.quantize(x, cb)
+    b = native.quantize(x.float(), cb)
+    torch.cuda.synchronize()
+    for key in ("idx", "best", "out"):
+        assert torch.equal(a[key], b[key]), key
+    assert a["out"].dtype == torch.float32
+    # strided head views (module layout) and the split-K path take the same route
+    xs = torch.randn((M, H, D), generator=g).to(dtype).cuda().permute(1, 0, 2)
+    c = native.quantize(xs, cb, flags=native.F_FORCE_SPLIT)
+    d = native.quantize(xs.float(), cb)
+    torch.cuda.synchronize()
+    assert torch.equal(c["idx"], d["idx"]) and torch.equal(c["out"], d["out"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_half_precision_module_inference_matches_float_path(dtype):
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(0)
+    for kw in (dict(dim=64), dict(dim=64, heads=2, codebook_dim=32, separate_codebook_per_head=True), dict(dim=64, heads=2, codebook_dim=32)):
+        mod = vq.VectorQuantize(codebook_params=CodebookParams(dim=kw.get("codebook_dim", 64), codebook_size=128), **kw).to(DEV).eval()
+        x = torch.randn(4, 100, 64, device=DEV).to(dtype)
+        with torch.no_grad():
+            q, i, loss = mod(x)
+            q2, i2, _ = mod(x.float())
+        assert torch.equal(i, i2) and torch.equal(q, q2) and q.dtype == torch.float32

@@ -161,7 +161,32 @@ def cfg1_latency():
           f"({8192 / t_g / 1e3:.1f} M rows/s)")
 
 
+def half_inference():
+    """cfg2 eval forward on bf16 activations: rows widened inside the search kernel vs a .float() pass in front of it."""
+    dev = "cuda:0"
+    mod = vq.VectorQuantize(dim=256, codebook_params=CodebookParams(dim=256, codebook_size=1024)).to(dev).eval()
+    xb = torch.randn(256, 1024, 256, device=dev).to(torch.bfloat16)
+    xf = xb.float()
+
+    def native_half():
+        with torch.no_grad():
+            mod(xb)
+
+    def cast_first():
+        with torch.no_grad():
+            mod(xb.float())
+
+    def fp32():
+        with torch.no_grad():
+            mod(xf)
+
+    t32, tc, th = timed(fp32, n=20, warm=10), timed(cast_first, n=20, warm=10), timed(native_half, n=20, warm=10)
+    print(f"cfg2 eval forward: fp32 rows {t32:.3f} ms | bf16 rows, .float() first {tc:.3f} ms | bf16 rows widened in the kernel "
+          f"{th:.3f} ms ({262144 / th / 1e3:.1f} M rows/s)")
+
+
 if __name__ == "__main__":
+    half_inference()
     main()
     train_steps()
     train_backward()

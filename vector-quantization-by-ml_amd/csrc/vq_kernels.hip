@@ -80,13 +80,13 @@ const DevInfo &dev_info() {
     return info;
 }
 
-template <int DP, int WAVES, int METRIC, bool MULTI, bool LSE = false>
+template <int DP, int WAVES, int METRIC, bool MULTI, bool LSE = false, int XT = 0>
 int launch_search_t(const SearchParams &p, int H, int splits, hipStream_t s) {
     using G = Geo<DP, WAVES>;
     const size_t lds = (size_t)G::MAIN_FLOATS * 4 + (size_t)WAVES * p.Q * 32 * 4 +
                        ((MULTI && p.loss_part) ? (size_t)WAVES * p.Q * 64 * 4 : 0);
     if (lds > 160 * 1024) return fail(VQ_E_UNSUPPORTED, "vq_search: LDS budget exceeded (too many residual stages)");
-    auto kern = vq_search_mfma<DP, WAVES, METRIC, MULTI, LSE>;
+    auto kern = vq_search_mfma<DP, WAVES, METRIC, MULTI, LSE, XT>;
     static thread_local bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -106,6 +106,14 @@ int launch_search_m(const SearchParams &p, int H, int splits, int metric, hipStr
     if (p.Q > 1) {
         if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, true>(p, H, splits, s);
         return launch_search_t<DP, WAVES, VQ_METRIC_DOT, true>(p, H, splits, s);
+    }
+    if (p.xt == 1) {  // fp16 rows, widened in the prologue (inference)
+        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, false, false, 1>(p, H, splits, s);
+        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, false, false, 1>(p, H, splits, s);
+    }
+    if (p.xt == 2) {  // bf16 rows
+        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, false, false, 2>(p, H, splits, s);
+        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, false, false, 2>(p, H, splits, s);
     }
     if (p.lse) {  // search + log-sum-exp in one sweep (cross-entropy commitment loss)
         if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, false, true>(p, H, splits, s);
@@ -223,7 +231,9 @@ void fill_search_params(SearchParams &p, const vq_args *a) {
     p.tiles_per_split = p.ntiles;
     p.pk_bytes = (unsigned)(vq_packed_floats(a->K, a->D) * 4);
     p.ste = (a->flags & VQ_F_STE) ? 1 : 0;
-    p.vec_x = (a->D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x)) ? 1 : 0;
+    p.xt = (a->flags & VQ_F_X_F16) ? 1 : ((a->flags & VQ_F_X_BF16) ? 2 : 0);
+    p.vec_x = (a->D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 &&
+               (p.xt ? (((uintptr_t)a->x & 7) == 0) : aligned16(a->x))) ? 1 : 0;
     p.vec_fin = (p.vec_x && (!a->out || (a->out_rs % 4 == 0 && a->out_hs % 4 == 0 && aligned16(a->out))) &&
                  (!a->cb || (a->cb_hs % 4 == 0 && a->cb_qs % 4 == 0 && aligned16(a->cb)))) ? 1 : 0;
 }
@@ -400,6 +410,9 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     hipStream_t s = (hipStream_t)stream;
     if (lse && (a->Q != 1 || padded_dim(a->D) == 0 || (a->flags & (VQ_F_FORCE_SIMPLE | VQ_F_FORCE_SPLIT))))
         return fail(VQ_E_UNSUPPORTED, "vq_quantize_lse: needs Q == 1, D <= 512 and the fused MFMA path");
+    if ((a->flags & (VQ_F_X_F16 | VQ_F_X_BF16)) &&
+        (a->Q != 1 || padded_dim(a->D) == 0 || lse || a->sq_err || (a->flags & (VQ_F_STE | VQ_F_FORCE_SIMPLE))))
+        return fail(VQ_E_UNSUPPORTED, "vq_quantize: 2-byte rows are inference only (Q == 1, D <= 512, no STE / sq_err / lse)");
     if (a->M > 0 && !a->idx) return fail(VQ_E_BADARG, "vq_quantize: idx is null");
     if (a->M > 0 && !a->cb) return fail(VQ_E_BADARG, "vq_quantize: natural codebook is null");
     if (a->M == 0) {

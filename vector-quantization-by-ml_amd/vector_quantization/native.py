@@ -18,6 +18,8 @@ F_STE = 1
 F_FORCE_SIMPLE = 2
 F_FORCE_SPLIT = 4
 F_SQERR_PER_HEAD = 8
+F_X_F16 = 16
+F_X_BF16 = 32
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get(
@@ -211,7 +213,15 @@ def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bo
                  lse [H, M] | None)
     """
     _require_gpu(x, cb)
-    assert x.dtype == torch.float32 and cb.dtype == torch.float32
+    assert cb.dtype == torch.float32
+    if x.dtype in (torch.float16, torch.bfloat16):
+        # 2-byte rows are widened inside the kernel's prologue (inference only); everything else takes fp32 rows
+        if ste or want_sq_err or want_lse or (flags & F_FORCE_SIMPLE) or x.shape[-1] > 512 or \
+                (idx is not None and idx.shape[-1] != 1) or (not stages_share_codebook and cb.shape[1] != 1):
+            x = x.float()
+        else:
+            flags |= F_X_F16 if x.dtype == torch.float16 else F_X_BF16
+    assert x.dtype in (torch.float32, torch.float16, torch.bfloat16)
     assert x.dim() == 3 and cb.dim() == 4 and cb.is_contiguous()
     H, M, D = x.shape
     Hc, Qc, K, Dc = cb.shape

@@ -162,8 +162,9 @@ class VectorQuantize(nn.Module):
         x4 = x.reshape(batch, n, heads, head_dim)
         x4 = cb.transform_input(x4)
         wide_input = x4.dtype == torch.float64  # the reference's straight-through sum x + (q - x) promotes to the input's width
-        if x4.dtype != torch.float32:
-            x4 = x4.float()
+        plain_inference = not self.training and indices is None and mask is None and cb.is_initialized
+        if x4.dtype != torch.float32 and not (plain_inference and x4.dtype in (torch.float16, torch.bfloat16)):
+            x4 = x4.float()  # (2-byte rows of a plain inference forward are widened inside the search kernel instead)
         if not x4.is_contiguous():
             x4 = x4.contiguous()
         rows = batch * n

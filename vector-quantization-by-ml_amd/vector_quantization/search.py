@@ -20,6 +20,7 @@ DOT = native.DOT
 
 class _NativeBackend:
     name = "hip-gfx950"
+    accepts_half_rows = True  # fp16 / bf16 rows are widened in the kernel's prologue (inference launches)
 
     @staticmethod
     def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None, want_lse=False,
@@ -172,13 +173,17 @@ def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, st
     similarities, both from the same sweep (what the cross-entropy commitment loss needs).
     ``sq_err_per_head``: sq_err is [H, Q] (one sum per head: GroupedResidualVQ reports a loss per group).
     """
-    if x.dtype != torch.float32:
-        x = x.float()
     if not cb.is_contiguous():
         cb = cb.contiguous()
     # x receives a gradient only through the straight-through output or the squared error: an eval-mode gather
     # (out = codebook[idx]) is not differentiable with respect to x, exactly like the reference's batched_embedding
     needs_grad = torch.is_grad_enabled() and ((x.requires_grad and (ste or want_sq_err)) or cb.requires_grad)
+    if x.dtype != torch.float32:
+        half_rows = (x.dtype in (torch.float16, torch.bfloat16) and getattr(_backend, "accepts_half_rows", False)
+                     and not needs_grad and not ste and not want_sq_err and not want_lse and cb.shape[1] == 1
+                     and (idx is None or idx.shape[-1] == 1))
+        if not half_rows:
+            x = x.float()  # the reference's x.float() (codebooks.py:354); the native inference launch does it in-kernel
     if needs_grad:
         res = _QuantizeFn.apply(x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out, idx, want_lse,
                                 sq_err_per_head)
