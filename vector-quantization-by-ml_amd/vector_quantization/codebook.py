@@ -86,7 +86,8 @@ def _pick_rows_all_ranks(rows: torch.Tensor, count: int) -> torch.Tensor:
     parts = []
     for src, n in enumerate(share):
         part = mine if src == rank else rows.new_empty((n, *rows.shape[1:]))
-        dist.broadcast(part, src=src)
+        if n > 0:  # (every rank knows the shares: empty ones are skipped consistently)
+            dist.broadcast(part, src=src)
         parts.append(part)
     return torch.cat(parts, dim=0)
 
