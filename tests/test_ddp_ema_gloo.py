@@ -127,3 +127,46 @@ def test_replicas_stay_identical_through_kmeans_seeding_and_dead_code_reseeding(
         for key in ("emb", "cs", "avg"):
             np.testing.assert_array_equal(a[key], b[key], err_msg=f"{key} (distributed_replace_codes={distributed_replace})")
         assert np.isfinite(a["emb"]).all() and float(np.abs(a["emb"]).max()) > 0
+
+
+def _worker_gpu(rank, world, port, out_dir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "vector-quantization-by-ml_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # two processes share the one GPU of the test box
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams, KmeansParameters
+
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    params = CodebookParams(dim=32, codebook_size=200, initialization_by_kmeans=True,
+                            kmeans_params=KmeansParameters(iter=3, sync=True), threshold_ema_dead_code=2)
+    mod = vq.VectorQuantize(dim=32, codebook_params=params).to(dev).train()
+    assert mod._codebook.use_ddp
+    for step in range(3):
+        torch.manual_seed(50 + step + 7 * rank)
+        with torch.no_grad():
+            mod(torch.randn(3 + rank, 40, 32, device=dev))
+    np.savez(os.path.join(out_dir, f"g{rank}.npz"), emb=mod._codebook.embeddings.cpu().numpy(),
+             cs=mod._codebook.cluster_size.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_native_replicas_stay_identical_on_the_gpu(tmp_path):
+    """The same replica-consistency property with the NATIVE kernels (EMA statistics, search) on the device: two
+    processes on the one GPU, collectives over gloo."""
+    port = _free_port()
+    mp.spawn(_worker_gpu, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "g0.npz"), np.load(tmp_path / "g1.npz")
+    np.testing.assert_array_equal(a["emb"], b["emb"])
+    np.testing.assert_array_equal(a["cs"], b["cs"])
