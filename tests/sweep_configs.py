@@ -61,6 +61,20 @@ def forward_cases():
     cases.append(("VectorQuantize", dict(dim=32, cb=dict(dim=32, codebook_size=40, decay=0.5, eps_for_smoothing=1e-3, **noexp)),
                   (2, 30, 32), {}))
     cases.append(("VectorQuantize", dict(dim=32, cb=dict(dim=32, codebook_size=40, ema_update=False, **noexp)), (2, 30, 32), {}))
+    # cosine similarity through the stacks (with and without the l2norm transforms), cosine + similarity-consuming losses
+    for l2 in (False, True):
+        cb = dict(dim=32, codebook_size=40, use_cosine_sim=True, **noexp)
+        if l2:
+            cb.update(transform_input="l2norm", weights_regularization="l2norm")
+        cases.append(("ResidualVQ", dict(dim=32, num_quantizers=3, cb=dict(cb)), (2, 30, 32), {}))
+        cases.append(("ResidualVQ", dict(dim=32, num_quantizers=3, shared_codebook=True, cb=dict(cb)), (2, 30, 32), {}))
+        cases.append(("GroupedResidualVQ", dict(dim=32, groups=2, num_quantizers=2, cb=dict(cb, dim=16)), (2, 30, 32), {}))
+    cases.append(("VectorQuantize", dict(dim=32, heads=2, codebook_dim=16, separate_codebook_per_head=True,
+                                         commitment_use_cross_entropy_loss=True,
+                                         cb=dict(dim=16, codebook_size=40, use_cosine_sim=True, **noexp)), (2, 30, 32), {}))
+    cases.append(("VectorQuantize", dict(dim=32, codebook_diversity_loss_weight=0.2, codebook_diversity_temperature=3.0,
+                                         cb=dict(dim=32, codebook_size=40, use_cosine_sim=True, transform_input="l2norm",
+                                                 weights_regularization="l2norm", **noexp)), (2, 30, 32), {}))
     return cases
 
 
