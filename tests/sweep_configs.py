@@ -95,7 +95,8 @@ def materialise_forward_kwargs(ctor, cb_kw, x, fwd):
     """Turn the placeholders into tensors (same seeds on every side of a comparison)."""
     kw = dict(fwd)
     if "mask" in kw:
-        kw["mask"] = torch.arange(x.shape[1])[None, :] < torch.tensor([x.shape[1], max(1, x.shape[1] // 2)])[:, None]
+        lengths = torch.tensor([max(1, x.shape[1] // (1 + i % 2)) for i in range(x.shape[0])])
+        kw["mask"] = torch.arange(x.shape[1])[None, :] < lengths[:, None]
     if kw.pop("given_indices", False):
         heads = ctor.get("heads", 1)
         n = (x.numel() // (x.shape[0] * x.shape[-1]) if ctor.get("channel_last", True)

@@ -118,3 +118,66 @@ def test_native_modules_equal_checker_backend_gradients(oracle):
             except AssertionError as e:
                 failures.append(f"#{i} {kind} {ctor} {fwd} {mode}: {e}")
     assert not failures, "\n".join(failures[:10])
+
+
+def _scaled(ctor, shape):
+    """The same configuration at realistic sizes: dim 32 -> 256, codebook dims x8, 40 codes -> 1000, 60 rows -> 4096
+    (other kernel instantiations: Dp = 128 / 256, multi-tile sweeps, tail masking at K % 32 != 0)."""
+    c = {k: (dict(v) if isinstance(v, dict) else v) for k, v in ctor.items()}
+    if c.get("dim") == 32:
+        c["dim"] = 256
+    if c.get("codebook_dim"):
+        c["codebook_dim"] *= 8
+    cb = c["cb"]
+    cb["dim"] *= 8
+    cb["codebook_size"] = 1000
+    if len(shape) == 3:
+        shape = (8, 512, 256)
+    elif len(shape) == 2:
+        shape = (4096, 256)
+    elif shape[1] == 32:  # channel-first image
+        shape = (8, 256, 16, 32)
+    else:
+        shape = (8, 16, 32, 256)
+    return c, shape
+
+
+@pytest.mark.parametrize("mode", ["eval", "train_ema"])
+def test_native_modules_equal_checker_backend_at_realistic_sizes(mode, oracle):
+    from vector_quantization import search
+
+    failures = []
+    picked = [c for c in forward_cases() if "given_indices" not in c[3] and not c[1].get("quantize_dropout")][::5]
+    n_run = 0
+    for i, (kind, ctor, shape, fwd) in enumerate(picked):
+        ctor, shape = _scaled(ctor, shape)
+        cpu_mod, ctor_kw, cb_kw = _build(kind, ctor)
+        if getattr(cpu_mod, "has_projections", False):
+            continue  # nn.Linear in front: MKL vs rocBLAS rounding moves near-ties at these sizes (not this library's kernels)
+        n_run += 1
+        gpu_mod = copy.deepcopy(cpu_mod).to(DEV)
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(11))
+        kw = materialise_forward_kwargs(ctor_kw, cb_kw, x, fwd)
+        grads = []
+        try:
+            for m, dev, backend in ((cpu_mod, "cpu", OracleBackend), (gpu_mod, DEV, None)):
+                m.train() if mode != "eval" else m.eval()
+                search.set_backend(backend)
+                try:
+                    xs = x.to(dev).clone().requires_grad_(mode != "eval")
+                    out = m(xs, **(_to_dev(kw) if dev != "cpu" else kw))
+                    if mode != "eval":
+                        w = torch.randn(out[0].shape, generator=torch.Generator().manual_seed(5)).to(dev)
+                        ((out[0] * w).sum() + out[2].sum() * 1.5).backward()
+                    grads.append((out, xs.grad))
+                finally:
+                    search.set_backend(None)
+            _close("out", grads[1][0], grads[0][0], tol=2e-5)
+            if mode != "eval":
+                _close("x.grad", grads[1][1], grads[0][1], tol=2e-5)
+                for (k, a), (_, b) in zip(gpu_mod.state_dict().items(), cpu_mod.state_dict().items()):
+                    _close(f"state[{k}]", a, b, tol=1e-4)
+        except AssertionError as e:
+            failures.append(f"#{i} {kind} {ctor} {shape} {fwd} {mode}: {e}")
+    assert n_run >= 8, n_run
+    assert not failures, "\n".join(failures[:10])
