@@ -369,3 +369,54 @@ def test_half_precision_module_inference_matches_float_path(dtype):
             q, i, loss = mod(x)
             q2, i2, _ = mod(x.float())
         assert torch.equal(i, i2) and torch.equal(q, q2) and q.dtype == torch.float32
+
+
+def test_c_abi_rejects_bad_arguments_without_launching():
+    """Argument errors come back as negative VQ_E_* codes with a message (include/vq_mi355x.h) -- never a launch."""
+    import ctypes
+
+    from vector_quantization import native
+
+    lib = native.load()
+    x = torch.randn(1, 64, 32, device=DEV)
+    cb = torch.randn(1, 1, 16, 32, device=DEV)
+    packed = native.pack_codebooks(cb, 0)
+    idx = torch.empty((1, 64, 1), dtype=torch.int64, device=DEV)
+    out = torch.empty_like(x)
+    ws = torch.empty(int(lib.vq_workspace_bytes(1, 64, 1)), dtype=torch.uint8, device=DEV)
+
+    def args(**over):
+        a = native.VqArgs()
+        a.H, a.Q, a.M, a.K, a.D, a.metric, a.flags = 1, 1, 64, 16, 32, 0, 0
+        a.x, a.x_rs, a.x_hs = x.data_ptr(), 32, 64 * 32
+        a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), 16 * 32, 0
+        a.packed, a.pk_hs, a.pk_qs = packed.data_ptr(), packed.shape[-1], 0
+        a.out, a.out_rs, a.out_hs = out.data_ptr(), 32, 64 * 32
+        a.idx, a.idx_rs, a.idx_hs, a.idx_qs = idx.data_ptr(), 1, 64, 0
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        for k, v in over.items():
+            setattr(a, k, v)
+        return a
+
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.vq_quantize_f32(ctypes.byref(args()), stream) == 0
+    BADARG, UNSUPPORTED = -1, -2
+    for over, want in ((dict(K=0), BADARG), (dict(D=-3), BADARG), (dict(metric=7), BADARG), (dict(idx=None), BADARG),
+                       (dict(cb=None), BADARG), (dict(packed=None), BADARG), (dict(workspace_bytes=16), BADARG),
+                       (dict(x=None), BADARG), (dict(flags=native.F_X_F16 | native.F_STE), UNSUPPORTED)):
+        rc = lib.vq_quantize_f32(ctypes.byref(args(**over)), stream)
+        assert rc == want, (over, rc)
+        assert lib.vq_last_error(), over
+    lse = torch.empty((1, 64), device=DEV)
+    assert lib.vq_quantize_lse_f32(ctypes.byref(args(Q=2)), ctypes.c_void_p(lse.data_ptr()), stream) == UNSUPPORTED
+    assert lib.vq_nearest_f32(ctypes.byref(args(Q=2)), stream) == BADARG
+    assert lib.vq_search_keys_f32(ctypes.byref(args()), 0, None, stream) == BADARG
+    assert lib.vq_similarities_f32(ctypes.byref(args()), None, 16, 64 * 16, stream) == BADARG
+    assert lib.vq_softmax_stats_f32(ctypes.byref(args()), ctypes.c_float(1.0), None, 0, 0, None, None, stream) == BADARG
+    assert lib.vq_packed_floats(0, 32) == 0 and lib.vq_workspace_bytes(0, 10, 1) == 0
+    torch.cuda.synchronize()  # nothing faulted
+    # the Python binding turns them into exceptions
+    with pytest.raises(RuntimeError):
+        native.quantize(x, cb, flags=native.F_FORCE_SIMPLE, want_lse=True)
+    with pytest.raises(native.NativeUnavailable):
+        native.quantize(x.cpu(), cb.cpu())
