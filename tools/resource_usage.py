@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Compile csrc/vq_kernels.hip with -Rpass-analysis=kernel-resource-usage and print one line per kernel:
+VGPRs, AGPRs, spilled VGPRs, scratch bytes/lane, occupancy, LDS.  `--spills` lists only kernels that spill.
+
+    python tools/resource_usage.py [--spills] [--filter SUBSTR] [extra hipcc flags ...]
+"""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "vector-quantization-by-ml_amd", "csrc", "vq_kernels.hip")
+
+
+def main():
+    args = sys.argv[1:]
+    only_spills = "--spills" in args
+    flt = None
+    if "--filter" in args:
+        flt = args[args.index("--filter") + 1]
+    extra = [a for a in args if a not in ("--spills", "--filter", flt)]
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-value", "-c",
+           "-Rpass-analysis=kernel-resource-usage", SRC, "-o", "/tmp/vq_resusage.o", *extra]
+    err = subprocess.run(cmd, capture_output=True, text=True).stderr
+    blocks = re.split(r"remark: [^\n]*Function Name: ", err)[1:]
+    names = [b.split("\n")[0].strip() for b in blocks]
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    print(f"{'kernel':90s} VGPR AGPR spill scratch occ   LDS")
+    for b, n in zip(blocks, dem):
+        def g(k):
+            m = re.search(k + r": (\d+)", b)
+            return int(m.group(1)) if m else -1
+        n = n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+        row = (g("VGPRs"), g("AGPRs"), g("VGPR Spill"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"),
+               g(r"LDS Size \[bytes/block\]"))
+        if only_spills and row[2] <= 0 and row[3] <= 0:
+            continue
+        if flt and flt not in n:
+            continue
+        print(f"{n[:90]:90s} {row[0]:4d} {row[1]:4d} {row[2]:5d} {row[3]:7d} {row[4]:3d} {row[5]:5d}")
+
+
+if __name__ == "__main__":
+    main()

@@ -80,10 +80,10 @@ const DevInfo &dev_info() {
     return info;
 }
 
-template <int DP, int WAVES, int METRIC, bool MULTI, bool LSE = false, int XT = 0>
+template <int DP, int WAVES, int METRIC, int MULTI, bool LSE = false, int XT = 0>
 int launch_search_t(const SearchParams &p, int H, int splits, hipStream_t s) {
     using G = Geo<DP, WAVES>;
-    const size_t lds = (size_t)G::MAIN_FLOATS * 4 + (size_t)WAVES * p.Q * 32 * 4 +
+    const size_t lds = (size_t)(MULTI ? G::MAIN_FLOATS_M : G::MAIN_FLOATS) * 4 + (size_t)WAVES * p.Q * 32 * 4 +
                        ((MULTI && p.loss_part) ? (size_t)WAVES * p.Q * 64 * 4 : 0);
     if (lds > 160 * 1024) return fail(VQ_E_UNSUPPORTED, "vq_search: LDS budget exceeded (too many residual stages)");
     auto kern = vq_search_mfma<DP, WAVES, METRIC, MULTI, LSE, XT>;
@@ -103,24 +103,28 @@ int launch_search_t(const SearchParams &p, int H, int splits, hipStream_t s) {
 
 template <int DP, int WAVES>
 int launch_search_m(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
-    if (p.Q > 1) {
-        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, true>(p, H, splits, s);
-        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, true>(p, H, splits, s);
+    if (p.Q > 1) {  // residual stages: eval (1) and straight-through (2) arithmetic are separate instantiations
+        if (p.ste) {
+            if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, 2>(p, H, splits, s);
+            return launch_search_t<DP, WAVES, VQ_METRIC_DOT, 2>(p, H, splits, s);
+        }
+        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, 1>(p, H, splits, s);
+        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, 1>(p, H, splits, s);
     }
     if (p.xt == 1) {  // fp16 rows, widened in the prologue (inference)
-        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, false, false, 1>(p, H, splits, s);
-        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, false, false, 1>(p, H, splits, s);
+        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, 0, false, 1>(p, H, splits, s);
+        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, 0, false, 1>(p, H, splits, s);
     }
     if (p.xt == 2) {  // bf16 rows
-        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, false, false, 2>(p, H, splits, s);
-        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, false, false, 2>(p, H, splits, s);
+        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, 0, false, 2>(p, H, splits, s);
+        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, 0, false, 2>(p, H, splits, s);
     }
     if (p.lse) {  // search + log-sum-exp in one sweep (cross-entropy commitment loss)
-        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, false, true>(p, H, splits, s);
-        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, false, true>(p, H, splits, s);
+        if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, 0, true>(p, H, splits, s);
+        return launch_search_t<DP, WAVES, VQ_METRIC_DOT, 0, true>(p, H, splits, s);
     }
-    if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, false>(p, H, splits, s);
-    return launch_search_t<DP, WAVES, VQ_METRIC_DOT, false>(p, H, splits, s);
+    if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, WAVES, VQ_METRIC_EUCLID, 0>(p, H, splits, s);
+    return launch_search_t<DP, WAVES, VQ_METRIC_DOT, 0>(p, H, splits, s);
 }
 
 int launch_search(int DP, int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
