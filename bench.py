@@ -1,26 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- vectors quantized / second on the nearest-codebook hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|k8192|cfg3a|cfg4|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|k8192|cfg3a|cfg3b|cfg4|cfg1] [--legs a,b,...]
 
 N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
-(one rank per GPU, RCCL).  A "step" is one full eval-mode module forward (codebook pack + fused
-search/gather launch) over one batch of synthetic input already resident in HBM.  Rank 0 prints ONE JSON line.
+(one rank per GPU, RCCL).  A "step" is one full eval-mode module forward (fused search/gather launch; the packed
+codebook image is cached by the module) over one batch of synthetic input already resident in HBM.  Rank 0 prints
+ONE JSON line.
 
-Default workload = BASELINE configs[1]: VectorQuantize(dim=256, codebook_size=1024) on a [256, 1024, 256]
-batch per GPU (M = 262 144 rows per GPU; rows shard over ranks with no data-path collective -> weak scaling).
+Headline workload = BASELINE configs[1]: VectorQuantize(dim=256, codebook_size=1024) on a [256, 1024, 256] batch per
+GPU (M = 262 144 rows per GPU; rows shard over ranks with no data-path collective -> weak scaling).
 
-Extra objects in the JSON line:
-  roofline      dominant kernel (vq_search_mfma) priced against the fp32 MFMA peak: algorithmic FLOPs
-                (2*K*D per searched row) / mean launch duration measured with HIP events on the launch stream.
+Objects in the JSON line beside the contract's keys:
+  roofline      dominant kernel (vq_search_mfma) priced against the fp32 MFMA peak: algorithmic FLOPs (2*K*D per
+                searched row and stage) / mean launch duration measured with HIP events on the launch stream INSIDE
+                the timed region.  `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of the same command
+                (profiles/traffic.json; gfx950 correction of MI355X_MICROARCH.md applied), null if not collected.
   cpu_baseline  the reference's ATen op sequence (oracle/ref_path.py, "port") timed on the host cores on a bounded
-                sample, rank 0 / N=1 only.
-  sharded_k65536  (informational) codebook K=65536, D=512 sharded over the N ranks with the packed-key
-                MIN all-reduce (BASELINE configs[4]); at N=1 this is the full-codebook 1-GPU figure.
+                sample, rank 0 / N = 1 only; also the 1-thread figure and the CPU model.
+  legs          (N = 1) the other single-GPU BASELINE workloads, each run like the headline (same W / K): k8192
+                (north-star roofline shape), cfg3a / cfg3b (multi-head, per-head dim 64 / 512), cfg4 (ResidualVQ) --
+                value, ms_per_step, roofline and a CPU-oracle parity gate per leg.
+  sharded_k65536  BASELINE configs[4]: K = 65536, D = 512 sharded over the N ranks (packed-key MIN all-reduce or
+                one-hop all-gather + local min); at N = 1 the full-codebook 1-GPU figure of the same kernels.
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -38,13 +45,20 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
-    # name: (kind, dim, K, batch shape, heads, Q)
-    "cfg2": dict(kind="vq", dim=256, K=1024, x_shape=(256, 1024, 256), desc="VectorQuantize dim=256 codebook_size=1024, batch [256,1024,256] per GPU, eval"),
-    "k8192": dict(kind="vq", dim=256, K=8192, x_shape=(256, 1024, 256), desc="VectorQuantize dim=256 codebook_size=8192, batch [256,1024,256] per GPU, eval (north-star roofline shape)"),
-    "cfg3a": dict(kind="vq", dim=512, K=8192, x_shape=(64, 1024, 512), heads=8, codebook_dim=64, desc="VectorQuantize dim=512 heads=8 codebook_dim=64 per-head codebooks K=8192, batch [64,1024,512] per GPU, eval"),
-    "cfg4": dict(kind="rvq", dim=256, K=1024, Q=8, x_shape=(64, 1024, 256), desc="ResidualVQ num_quantizers=8 codebook_size=1024 dim=256, batch [64,1024,256] per GPU, eval"),
+    "cfg2": dict(kind="vq", dim=256, K=1024, x_shape=(256, 1024, 256),
+                 desc="VectorQuantize dim=256 codebook_size=1024, batch [256,1024,256] per GPU, eval"),
+    "k8192": dict(kind="vq", dim=256, K=8192, x_shape=(256, 1024, 256),
+                  desc="VectorQuantize dim=256 codebook_size=8192, batch [256,1024,256] per GPU, eval (north-star roofline shape)"),
+    "cfg3a": dict(kind="vq", dim=512, K=8192, x_shape=(64, 1024, 512), heads=8, codebook_dim=64,
+                  desc="VectorQuantize dim=512 heads=8 codebook_dim=64 per-head codebooks K=8192, batch [64,1024,512] per GPU, eval"),
+    "cfg3b": dict(kind="vq", dim=512, K=8192, x_shape=(64, 1024, 512), heads=8, codebook_dim=512,
+                  desc="VectorQuantize dim=512 heads=8 codebook_dim=512 (Linear 512->4096->512 projections) per-head codebooks "
+                       "K=8192, batch [64,1024,512] per GPU, eval; value = whole module forward, roofline = search kernel only"),
+    "cfg4": dict(kind="rvq", dim=256, K=1024, Q=8, x_shape=(64, 1024, 256),
+                 desc="ResidualVQ num_quantizers=8 codebook_size=1024 dim=256, batch [64,1024,256] per GPU, eval"),
     "cfg1": dict(kind="vq", dim=64, K=256, x_shape=(32, 256, 64), desc="VectorQuantize dim=64 codebook_size=256, batch [32,256,64], eval"),
 }
+DEFAULT_LEGS = "k8192,cfg3a,cfg3b,cfg4"
 
 
 def log(*a):
@@ -60,6 +74,7 @@ def build_module(w, device, seed=4321):
         heads = w.get("heads", 1)
         cd = w.get("codebook_dim", None)
         d = cd if cd is not None else w["dim"]
+        torch.manual_seed(seed)  # projection weights of cfg3b
         mod = vq.VectorQuantize(dim=w["dim"], codebook_params=CodebookParams(dim=d, codebook_size=w["K"]), heads=heads,
                                 codebook_dim=cd, separate_codebook_per_head=heads > 1)
         with torch.no_grad():
@@ -72,32 +87,49 @@ def build_module(w, device, seed=4321):
     return mod.to(device).eval()
 
 
-def rows_per_step(w):
+def tokens_per_step(w):
     n = 1
     for s in w["x_shape"][:-1]:
         n *= s
-    return n * w.get("heads", 1) if w["kind"] == "vq" else n
+    return n
+
+
+def rows_per_step(w):
+    return tokens_per_step(w) * (w.get("heads", 1) if w["kind"] == "vq" else 1)
+
+
+def head_dim(w):
+    return w.get("codebook_dim", None) or w["dim"]
 
 
 def flops_per_step(w):
-    heads = w.get("heads", 1)
-    d = w.get("codebook_dim", None) or w["dim"]
-    tokens = 1
-    for s in w["x_shape"][:-1]:
-        tokens *= s
-    return 2.0 * tokens * heads * w["K"] * d * w.get("Q", 1)
+    return 2.0 * tokens_per_step(w) * w.get("heads", 1) * w["K"] * head_dim(w) * w.get("Q", 1)
 
 
-def kernel_roofline(w, device, mod, x):
-    """Mean duration of the dominant kernel (vq_search_mfma) alone, HIP events on the launch stream."""
+def algorithmic_bytes_per_step(w):
+    """per searched row read x, write q, write one int64 per stage: 8 D + 8 Q (+ the codebook once)."""
+    return (8 * head_dim(w) + 8 * w.get("Q", 1)) * rows_per_step(w)
+
+
+def traffic_record(name):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def isolated_kernel_ms(w, device, mod, x, n=10):
+    """Back-to-back launches of the search kernel alone through the C ABI (informational cross-check of the live figure)."""
     from vector_quantization import native
 
     heads = w.get("heads", 1)
     if w["kind"] == "vq":
         cb = mod._codebook.embeddings.detach()[:, None].contiguous()  # [H, 1, K, D]
         d = cb.shape[-1]
-        rows = x.numel() // (heads * d)
-        flat = x.reshape(rows, heads, d).permute(1, 0, 2)
+        xin = mod.project_in(x)
+        rows = xin.numel() // (heads * d)
+        flat = xin.reshape(rows, heads, d).permute(1, 0, 2)
     else:
         cb = torch.stack([layer._codebook.embeddings.detach()[0] for layer in mod.layers])[None].contiguous()
         flat = x.reshape(1, -1, x.shape[-1])
@@ -107,27 +139,13 @@ def kernel_roofline(w, device, mod, x):
     for _ in range(3):
         native.quantize(flat, cb, packed=packed, want_best=False, out=out, idx=idx)
     torch.cuda.synchronize(device)
-    n = 10
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
         native.quantize(flat, cb, packed=packed, want_best=False, out=out, idx=idx)
     e1.record()
     torch.cuda.synchronize(device)
-    ms = e0.elapsed_time(e1) / n
-    fl = flops_per_step(w)
-    achieved = fl / (ms * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(w["name"], {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    return dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, kernel="vq_search_mfma",
-                kernel_ms=round(ms, 4), algorithmic_flops_per_launch=fl,
-                algorithmic_hbm_bytes_per_launch=(8 * (w.get("codebook_dim") or w["dim"]) + 8 * w.get("Q", 1)) * rows_per_step(w))
+    return e0.elapsed_time(e1) / n
 
 
 def usable_cores() -> int:
@@ -154,13 +172,22 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(w, budget_s):
-    """The reference's ATen op sequence on the host cores, bounded sample of the same workload."""
+    """The reference's ATen op sequence on the host cores, bounded sample of the same workload; all usable threads
+    (the reported value) and one thread."""
     from oracle import ref_path
 
     cores = usable_cores()
-    torch.set_num_threads(cores)
-
     dim, K = w["dim"], w["K"]
     g = torch.Generator().manual_seed(1234)
     if w["kind"] == "rvq":
@@ -170,9 +197,9 @@ def cpu_baseline(w, budget_s):
         fn = lambda: ref_path.residual_vq_forward(x, cbs)  # noqa: E731
     else:
         heads = w.get("heads", 1)
-        d = w.get("codebook_dim", None) or dim
+        d = head_dim(w)
         b = max(1, min(w["x_shape"][0], 65536 // w["x_shape"][1]))
-        sample_shape = (b, w["x_shape"][1], dim)
+        sample_shape = (b, w["x_shape"][1], heads * d)
         cb = torch.randn((heads, K, d), generator=g)
         x = torch.randn(sample_shape, generator=g)
 
@@ -180,50 +207,115 @@ def cpu_baseline(w, budget_s):
             flat = x.reshape(-1, heads, d).permute(1, 0, 2)
             return ref_path.codebook_forward(flat, cb)
     rows = sample_shape[0] * sample_shape[1] * (w.get("heads", 1) if w["kind"] == "vq" else 1)
-    fn()  # warm-up
-    t0 = time.perf_counter()
-    it = 0
-    while True:
-        fn()
-        it += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or it >= 200:
-            break
-    return dict(value=round(rows * it / el, 1), unit="vectors/s", cores=cores, kind="port",
-                sample=f"oracle/ref_path.py (reference ATen op sequence: -cdist, argmax, one_hot, gather) on x{list(sample_shape)}, "
-                       f"{it} iterations in {el:.1f} s, torch {torch.__version__} CPU, {cores} threads "
-                       f"(machine reports {os.cpu_count()} cpus)")
+
+    def timed(threads, budget):
+        torch.set_num_threads(threads)
+        fn()  # warm-up
+        t0 = time.perf_counter()
+        it = 0
+        while True:
+            fn()
+            it += 1
+            el = time.perf_counter() - t0
+            if el >= budget or it >= 200:
+                break
+        return rows * it / el, it, el
+
+    v_all, it, el = timed(cores, budget_s)
+    v_one, it1, el1 = timed(1, max(2.0, budget_s / 2.0))
+    torch.set_num_threads(cores)
+    return dict(value=round(v_all, 1), unit="vectors/s", cores=cores, kind="port", one_thread_value=round(v_one, 1),
+                cpu_model=cpu_model(),
+                sample=f"oracle/ref_path.py (reference ATen op sequence: -cdist, argmax, one_hot, gather) on x{list(sample_shape)}: "
+                       f"{it} iterations in {el:.1f} s with {cores} threads, {it1} in {el1:.1f} s with 1 thread; "
+                       f"torch {torch.__version__} CPU on {cpu_model()} (machine reports {os.cpu_count()} cpus)")
 
 
 def parity_gate(w, mod, x):
-    """Part of the cpu_baseline leg (rank 0, N = 1): the CPU oracle is the CHECKER for a sample of the GPU result."""
+    """rank 0, N = 1: the CPU oracle is the CHECKER for a sample of the GPU result (never the thing measured)."""
     from oracle import vq_oracle
 
+    kind, heads = w["kind"], w.get("heads", 1)
     with torch.no_grad():
-        sample = x[:2]
-        out_s = mod(sample)
-    if w["kind"] == "vq" and w.get("heads", 1) == 1:
-        ref = vq_oracle.vq_forward(sample.reshape(1, -1, w["dim"]).cpu().numpy(), mod._codebook.embeddings.cpu().numpy())
-        ok = bool((out_s[1].reshape(-1).cpu().numpy() == ref["idx"][0]).all())
-        n_s = ref["idx"].size
-    elif w["kind"] == "rvq":
-        cbs = torch.stack([layer._codebook.embeddings[0] for layer in mod.layers]).cpu().numpy()
-        ref = vq_oracle.rvq_forward(sample.reshape(-1, w["dim"]).cpu().numpy(), cbs)
-        ok = bool((out_s[1].reshape(-1, w["Q"]).cpu().numpy() == ref["idx"]).all())
-        n_s = ref["idx"].size
-    else:
-        h, d = w["heads"], w["codebook_dim"]
-        flat = sample.reshape(-1, h, d).permute(1, 0, 2).contiguous().cpu().numpy()
-        ref = vq_oracle.vq_forward(flat, mod._codebook.embeddings.cpu().numpy())
-        ok = bool((out_s[1].reshape(-1, h).cpu().numpy() == ref["idx"].T).all())
-        n_s = ref["idx"].size
+        if kind == "vq" and heads == 1:
+            sample = x[:2]
+            got = mod(sample)[1].reshape(-1).cpu().numpy()
+            ref = vq_oracle.vq_forward(sample.reshape(1, -1, w["dim"]).cpu().numpy(), mod._codebook.embeddings.cpu().numpy())
+            ok, n_s = bool((got == ref["idx"][0]).all()), ref["idx"].size
+        elif kind == "rvq":
+            sample = x[:2]
+            got = mod(sample)[1].reshape(-1, w["Q"]).cpu().numpy()
+            cbs = torch.stack([layer._codebook.embeddings[0] for layer in mod.layers]).cpu().numpy()
+            ref = vq_oracle.rvq_forward(sample.reshape(-1, w["dim"]).cpu().numpy(), cbs)
+            ok, n_s = bool((got == ref["idx"]).all()), ref["idx"].size
+        else:
+            h, d = heads, head_dim(w)
+            sample = x[:2] if d <= 64 else x[:1, :256]
+            got = mod(sample)[1].reshape(-1, h).cpu().numpy()
+            # the rows the search sees: after the (GPU) input projection, split into heads
+            flat = mod.project_in(sample).reshape(-1, h, d).permute(1, 0, 2).contiguous().cpu().numpy()
+            ref = vq_oracle.vq_forward(flat, mod._codebook.embeddings.cpu().numpy())
+            ok, n_s = bool((got == ref["idx"].T).all()), ref["idx"].size
     if not ok:
-        raise SystemExit("PARITY FAILURE: GPU indices differ from the CPU oracle; refusing to report a number")
+        raise SystemExit(f"PARITY FAILURE ({w['name']}): GPU indices differ from the CPU oracle; refusing to report a number")
     return f"indices bit-exact vs CPU oracle on a {n_s}-index sample"
 
 
+def run_workload(name, args, device, rank, world, want_parity):
+    """W warm-up + K timed steps of one workload; -> (value rows/s over all ranks, ms_per_step, roofline, parity, w)."""
+    from vector_quantization import native
+
+    w = dict(WORKLOADS[name], name=name)
+    mod = build_module(w, device)
+    x = torch.randn(w["x_shape"], generator=torch.Generator().manual_seed(1234 + rank)).to(device)
+    with torch.no_grad():
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:  # not part of W or K: lets the clock ramp up
+            mod(x)
+            torch.cuda.synchronize(device)
+        for _ in range(args.warmup):
+            mod(x)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        native.begin_kernel_timing()  # HIP events around the search launch, on its own stream, inside the timed region
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mod(x)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+        kernel_events = native.end_kernel_timing()
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    value = rows_per_step(w) * args.steps * world / elapsed
+
+    fl = flops_per_step(w)
+    live_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(1, len(kernel_events))
+    with torch.no_grad():
+        iso_ms = isolated_kernel_ms(w, device, mod, x)
+    achieved = fl / (live_ms * 1e-3) / 1e12
+    ab = algorithmic_bytes_per_step(w)
+    roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic_record(name), kernel="vq_search_mfma",
+                kernel_ms=round(live_ms, 4), kernel_ms_isolated=round(iso_ms, 4), launches_timed=len(kernel_events),
+                algorithmic_flops_per_launch=fl, algorithmic_hbm_bytes_per_launch=ab,
+                hbm_gbs_algorithmic=round(ab / (live_ms * 1e-3) / 1e9, 1), hbm_frac_of_peak=round(ab / (live_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+    parity = parity_gate(w, mod, x) if want_parity else None
+    del mod, x
+    gc.collect()
+    torch.cuda.empty_cache()
+    return value, elapsed / args.steps * 1e3, roof, parity, w
+
+
 def sharded_k65536(device, rank, world, steps=5):
-    """BASELINE configs[4]: K=65536, D=512 sharded over the ranks, packed-key MIN all-reduce over RCCL."""
+    """BASELINE configs[4]: K=65536, D=512 sharded over the ranks; both exchange variants (RCCL MIN all-reduce of the
+    packed keys, one-hop all-gather + local min)."""
     from vector_quantization.sharded import ShardedCodebookSearch
 
     K, D, M = 65536, 512, 8192
@@ -233,26 +325,34 @@ def sharded_k65536(device, rank, world, steps=5):
     x = torch.randn((M, D), generator=torch.Generator().manual_seed(1234)).to(device)
     shard = full[rank * kl:(rank + 1) * kl].to(device)
     table = full.to(device)  # replicated gather table (128 MiB)
-    s = ShardedCodebookSearch(shard, full_codebook=table)
-    for _ in range(2):
-        s(x)
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out, idx, best, _ = s(x)
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    t = torch.tensor([el], device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
-    return dict(value=round(M * steps / el, 1), unit="vectors/s", n_gpus=world, ms_per_step=round(el / steps * 1e3, 3),
-                config="K=65536 D=512 M=8192 tokens replicated, codebook sharded K/N per GPU, 8-byte key MIN all-reduce, replicated gather table",
-                idx_checksum=int(idx.sum().item()))
+    res = {}
+    for mode in ("all_reduce", "all_gather"):
+        s = ShardedCodebookSearch(shard, full_codebook=table, reduction=mode)
+        for _ in range(3):
+            s(x)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, idx, best, _ = s(x)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        res[mode] = dict(value=round(M * steps / el, 1), ms_per_step=round(el / steps * 1e3, 3), idx_checksum=int(idx.sum().item()))
+        if world == 1:
+            break  # no exchange at N = 1: the two variants are the same launches
+    best_mode = max(res, key=lambda m: res[m]["value"])
+    return dict(value=res[best_mode]["value"], unit="vectors/s", n_gpus=world, ms_per_step=res[best_mode]["ms_per_step"],
+                reduction=best_mode, variants=res,
+                roofline_frac=round(2.0 * K * D * res[best_mode]["value"] / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                config="K=65536 D=512 M=8192 tokens replicated, codebook sharded K/N per GPU, 8-byte packed (distance, index) keys "
+                       "reduced over the ranks, replicated gather table")
 
 
 def main():
@@ -261,6 +361,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=30)  # the chip needs ~30 ms of load to settle its clock
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--legs", default=None, help=f"comma list of extra workloads (N = 1 only; default {DEFAULT_LEGS} beside cfg2)")
+    ap.add_argument("--no-legs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
@@ -290,62 +392,33 @@ def main():
     from vector_quantization import native
 
     native.load()
-    w = dict(WORKLOADS[args.workload], name=args.workload)
-    mod = build_module(w, device)
-    x = torch.randn(w["x_shape"], generator=torch.Generator().manual_seed(1234 + rank)).to(device)
+    solo = rank == 0 and world == 1
+    value, ms_per_step, roof, parity, w = run_workload(args.workload, args, device, rank, world, want_parity=solo and not args.no_cpu_baseline)
 
-    parity = None
+    legs = None
+    leg_names = [] if (args.no_legs or world > 1) else [n for n in (args.legs if args.legs is not None else
+                                                                    (DEFAULT_LEGS if args.workload == "cfg2" else "")).split(",") if n]
+    if leg_names:
+        legs = {}
+        for n in leg_names:
+            try:
+                v, ms, r, par, wl = run_workload(n, args, device, rank, world, want_parity=not args.no_cpu_baseline)
+                legs[n] = dict(value=round(v, 1), unit="vectors/s", ms_per_step=round(ms, 4), workload=wl["desc"],
+                               rows_per_step=rows_per_step(wl), roofline=r, parity=par)
+            except SystemExit:
+                raise
+            except Exception as e:  # a leg never takes the headline line down with it
+                legs[n] = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
 
-    # ---- timed region ------------------------------------------------------------------------------------------
-    with torch.no_grad():
-        t_settle = time.perf_counter()
-        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:  # not part of W or K: lets the clock ramp up
-            mod(x)
-            torch.cuda.synchronize(device)
-        for _ in range(args.warmup):
-            mod(x)
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        native.begin_kernel_timing()  # HIP events around the search launch, on its own stream, inside the timed region
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            mod(x)
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        elapsed = time.perf_counter() - t0
-        kernel_events = native.end_kernel_timing()
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    total_rows = rows_per_step(w) * args.steps * world
-    value = total_rows / elapsed
-
-    roof = None
-    with torch.no_grad():
-        roof = kernel_roofline(w, device, mod, x)
-    if kernel_events:
-        # the figure of record: mean duration of the search launch DURING the timed steps
-        live_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / len(kernel_events)
-        roof["kernel_ms_isolated"] = roof["kernel_ms"]
-        roof["kernel_ms"] = round(live_ms, 4)
-        roof["achieved"] = round(roof["algorithmic_flops_per_launch"] / (live_ms * 1e-3) / 1e12, 2)
-        roof["frac"] = round(roof["achieved"] / PEAK_F32_MFMA_TFLOPS, 4)
-        roof["launches_timed"] = len(kernel_events)
     sharded = None
     if not args.no_sharded:
         try:
             with torch.no_grad():
                 sharded = sharded_k65536(device, rank, world)
         except Exception as e:  # informational leg: never fail the bench line
-            sharded = dict(error=str(e)[:200])
+            sharded = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        parity = parity_gate(w, mod, x)
+    if solo and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, args.cpu_seconds)
 
     if rank == 0:
@@ -356,7 +429,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -367,6 +440,7 @@ def main():
             "parity": parity,
             "roofline": roof,
             "cpu_baseline": cpu,
+            "legs": legs,
             "sharded_k65536": sharded,
             "device": native.device_info(),
         }

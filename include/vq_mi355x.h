@@ -114,6 +114,12 @@ int vq_quantize_lse_f32(const vq_args *a, float *lse, void *stream);
 int vq_nearest_f32(const vq_args *a, void *stream);
 int vq_residual_f32(const vq_args *a, void *stream);
 
+/* Largest number of residual stages ONE fused launch can hold for rows of dimension D (the winners' indices and, with
+ * want_sq_err, the loss partials of every stage live in the CU's 160 KiB of LDS).  0 when D has no MFMA path (D > 512).
+ * A caller with more stages (the reference's ResidualVQ has no limit, residual_vq.py:212-243) runs its layers one
+ * launch each instead.  Host-side arithmetic only: no device call. */
+int vq_max_fused_stages(int D, int want_sq_err);
+
 /*
  * Codebook-sharded search, step 1: search only the local shard and emit one packed SIGNED 64-bit key
  * per row:  hi = order image of the value ("smaller wins", top bit flipped), lo = code index + idx_offset.

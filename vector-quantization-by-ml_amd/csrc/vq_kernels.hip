@@ -80,6 +80,22 @@ const DevInfo &dev_info() {
     return info;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device property of a kernel: one flag per device ordinal
+// (per thread and per instantiation), so a process that drives several GPUs raises the limit on each of them.
+constexpr int kMaxDevices = 64;
+
+template <typename K>
+int allow_big_lds(K kern, bool (&done)[kMaxDevices]) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(VQ_E_NODEVICE, "vq: no HIP device");
+    const bool tracked = dev >= 0 && dev < kMaxDevices;
+    if (tracked && done[dev]) return 0;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+    if (tracked) done[dev] = true;
+    return 0;
+}
+
 template <int DP, int WAVES, int METRIC, int MULTI, bool LSE = false, int XT = 0>
 int launch_search_t(const SearchParams &p, int H, int splits, hipStream_t s) {
     using G = Geo<DP, WAVES>;
@@ -87,18 +103,27 @@ int launch_search_t(const SearchParams &p, int H, int splits, hipStream_t s) {
                        ((MULTI && p.loss_part) ? (size_t)WAVES * p.Q * 64 * 4 : 0);
     if (lds > 160 * 1024) return fail(VQ_E_UNSUPPORTED, "vq_search: LDS budget exceeded (too many residual stages)");
     auto kern = vq_search_mfma<DP, WAVES, METRIC, MULTI, LSE, XT>;
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
-        attr_done = true;
-    }
+    static thread_local bool attr_done[kMaxDevices] = {};
+    if (int rc = allow_big_lds(kern, attr_done)) return rc;
     const long long rows_per_wg = 32ll * WAVES;
     dim3 grid((unsigned)((p.M + rows_per_wg - 1) / rows_per_wg), (unsigned)H, (unsigned)splits);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "vq_search_mfma launch");
     return 0;
+}
+
+// LDS bytes of a residual (multi-stage) launch with Q stages; the budget is the CU's 160 KiB
+template <int DP, int WAVES>
+constexpr size_t multi_lds_bytes(int Q, bool with_loss) {
+    return (size_t)Geo<DP, WAVES>::MAIN_FLOATS_M * 4 + (size_t)WAVES * Q * 32 * 4 + (with_loss ? (size_t)WAVES * Q * 64 * 4 : 0);
+}
+
+template <int DP, int WAVES>
+int max_stages_t(bool with_loss) {
+    int q = 1;
+    while (q < 4096 && multi_lds_bytes<DP, WAVES>(q + 1, with_loss) <= 160 * 1024) ++q;
+    return q;
 }
 
 template <int DP, int WAVES>
@@ -144,12 +169,8 @@ int launch_aux_t(const AuxParams &p, int H, hipStream_t s) {
     using G = Geo<DP, WAVES>;
     const size_t lds = (size_t)G::MAIN_FLOATS * 4;
     auto kern = vq_sweep_aux<DP, WAVES, METRIC, MODE>;
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
-        attr_done = true;
-    }
+    static thread_local bool attr_done[kMaxDevices] = {};
+    if (int rc = allow_big_lds(kern, attr_done)) return rc;
     const long long rows_per_wg = 32ll * WAVES;
     dim3 grid((unsigned)((p.M + rows_per_wg - 1) / rows_per_wg), (unsigned)H, 1);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, s, p);
@@ -186,12 +207,8 @@ int launch_ce_bwd_t(const CeBwdParams &p, int H, hipStream_t s) {
     const size_t stage_floats = (size_t)4 * (32 * CeGeo<DP>::GS + 96);
     const size_t lds = 4 * ((size_t)G::MAIN_FLOATS > stage_floats ? (size_t)G::MAIN_FLOATS : stage_floats);
     auto kern = vq_ce_backward<DP, METRIC>;
-    static thread_local bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
-        attr_done = true;
-    }
+    static thread_local bool attr_done[kMaxDevices] = {};
+    if (int rc = allow_big_lds(kern, attr_done)) return rc;
     dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)H, (unsigned)CeGeo<DP>::NH);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     hipError_t e = hipGetLastError();
@@ -552,13 +569,8 @@ int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int6
             row_blocks = (M + rows_per_block - 1) / rows_per_block;
             const size_t per_wave = (size_t)cw * D4 + ((cw + 3) & ~3) + 64 * 2 + 64;
             const size_t lds = per_wave * 4 * 4;
-            static thread_local bool attr_done = false;
-            if (!attr_done) {
-                hipError_t e = hipFuncSetAttribute((const void *)vq_ema_accumulate_owner_kernel,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
-                attr_done = true;
-            }
+            static thread_local bool attr_done[kMaxDevices] = {};
+            if (int arc = allow_big_lds(vq_ema_accumulate_owner_kernel, attr_done)) return arc;
             hipLaunchKernelGGL(vq_ema_accumulate_owner_kernel,
                                dim3((unsigned)((owners + 3) / 4), (unsigned)row_blocks, (unsigned)H), dim3(256), lds, s, x,
                                (long long)x_rs, (long long)x_hs, (const long long *)idx, (long long)idx_rs,
@@ -705,6 +717,18 @@ int vq_ce_backward_f32(const vq_args *a, const float *lse, const float *target_l
         case 512: return launch_ce_bwd_m<512>(p, a->H, a->metric, s);
     }
     return fail(VQ_E_UNSUPPORTED, "vq_ce_backward: unsupported padded dim");
+}
+
+int vq_max_fused_stages(int D, int want_sq_err) {
+    // largest Q one residual launch can hold (winner indices and loss partials of every stage live in LDS); 0: no MFMA path
+    switch (padded_dim(D)) {
+        case 32: return max_stages_t<32, 8>(want_sq_err != 0);
+        case 64: return max_stages_t<64, 8>(want_sq_err != 0);
+        case 128: return max_stages_t<128, 8>(want_sq_err != 0);
+        case 256: return max_stages_t<256, 8>(want_sq_err != 0);
+        case 512: return max_stages_t<512, 4>(want_sq_err != 0);
+    }
+    return 0;
 }
 
 int vq_nearest_f32(const vq_args *a, void *stream) {

@@ -34,6 +34,11 @@ class GraphedForward:
                 module(self.static_in, **forward_kwargs)
         torch.cuda.current_stream(example.device).wait_stream(side)
         torch.cuda.synchronize(example.device)
+        # the modules cache the packed image of an unchanged codebook; the graph must contain the pack itself, so that a
+        # replay reads the weights of its own time (in-place updates need no re-capture): drop the caches before capturing
+        for m in module.modules():
+            if hasattr(m, "invalidate_packed"):
+                m.invalidate_packed()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = module(self.static_in, **forward_kwargs)

@@ -127,6 +127,8 @@ def load():
         lib.vq_quantize_backward_f32.restype = ctypes.c_int
         lib.vq_ema_accumulate_residual_f32.argtypes = [ap, _vp, _vp, _vp]
         lib.vq_ema_accumulate_residual_f32.restype = ctypes.c_int
+        lib.vq_max_fused_stages.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.vq_max_fused_stages.restype = ctypes.c_int
         lib.vq_device_info.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         lib.vq_device_info.restype = ctypes.c_int
         _lib = lib
@@ -138,7 +140,7 @@ EXPORTED_SYMBOLS = (
     "vq_residual_f32", "vq_keys_init", "vq_search_keys_f32", "vq_finalize_keys_f32", "vq_last_error",
     "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32", "vq_similarities_f32", "vq_softmax_stats_f32",
     "vq_ce_backward_f32", "vq_quantize_lse_f32",
-    "vq_quantize_backward_f32", "vq_ema_accumulate_residual_f32",
+    "vq_quantize_backward_f32", "vq_ema_accumulate_residual_f32", "vq_max_fused_stages",
 )
 
 
@@ -167,6 +169,11 @@ def device_info() -> str:
     buf = ctypes.create_string_buffer(256)
     _check(load().vq_device_info(buf, 256), "vq_device_info")
     return buf.value.decode()
+
+
+def max_fused_stages(D: int, want_sq_err: bool) -> int:
+    """Largest residual stack one fused launch holds for rows of dimension D (host arithmetic in the library, no device call)."""
+    return int(load().vq_max_fused_stages(int(D), 1 if want_sq_err else 0))
 
 
 def packed_floats(K: int, D: int) -> int:

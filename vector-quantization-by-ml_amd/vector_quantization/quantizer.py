@@ -27,6 +27,18 @@ LossBreakdown = namedtuple(
 )
 
 
+def _cached_zeros(module, attr: str, shape, device) -> torch.Tensor:
+    """A persistent all-zero fp32 tensor for the loss an inference forward returns (the reference allocates one per call,
+    i.e. a fill kernel per forward).  Re-created if the caller modified the previous one in place."""
+    entry = getattr(module, attr, None)
+    if (entry is None or entry[0].device != device or tuple(entry[0].shape) != tuple(shape)
+            or entry[0]._version != entry[1]):
+        t = torch.zeros(shape, dtype=torch.float32, device=device)
+        entry = (t, t._version)
+        setattr(module, attr, entry)
+    return entry[0]
+
+
 def _world_is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
@@ -105,6 +117,7 @@ class VectorQuantize(nn.Module):
             in_place_codebook_optimizer(self._codebook.parameters()) if in_place_codebook_optimizer is not None else None
         )
         self.register_buffer("zero", torch.tensor(0.0), persistent=False)
+        self._zero_loss = None
 
     # ------------------------------------------------------------------ codebook access (repaired w.r.t. the fork)
     @property
@@ -195,7 +208,10 @@ class VectorQuantize(nn.Module):
             cb.seed_with_kmeans(flat.detach(), flat_mask)
             cb.is_initialized = True
 
-        loss = torch.zeros(1, device=x.device, dtype=torch.float32)
+        if training or return_loss:
+            loss = torch.zeros(1, device=x.device, dtype=torch.float32)
+        else:  # inference: nothing is ever added to it -- a persistent zero instead of a fill kernel per forward
+            loss = _cached_zeros(self, "_zero_loss", (1,), x.device)
         commit_loss = diversity_loss = orthogonal_loss = inplace_loss = self.zero
         cb_grad_from_err = self.learnable_codebook and not freeze_codebook
         will_update = training and cb.ema_update and not freeze_codebook

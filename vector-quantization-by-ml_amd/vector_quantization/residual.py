@@ -21,7 +21,7 @@ import torch.distributed as dist
 from torch import nn
 
 from . import search
-from .quantizer import VectorQuantize
+from .quantizer import VectorQuantize, _cached_zeros
 
 
 def _round_up(value: int, multiple: int) -> int:
@@ -78,6 +78,8 @@ class ResidualVQ(nn.Module):
             first = self.layers[0]._codebook
             for layer in self.layers[1:]:
                 layer._codebook = first
+        self._stage_cache = None   # (key, stacked natural codebooks [1, Q|1, K, D], packed images) of the fused launch
+        self._zero_losses = None
 
     # ------------------------------------------------------------------ codes
     @property
@@ -111,6 +113,11 @@ class ResidualVQ(nn.Module):
             return False
         first = self.layers[0]
         cb0 = first._codebook
+        # the kernel keeps every stage's winners (and loss partials) in LDS: stacks beyond its budget (e.g. 32 stages of
+        # dim 256 with the commitment loss) run layer by layer, one launch each, like the reference's loop
+        limit = getattr(search.get_backend(), "max_fused_stages", None)
+        if limit is not None and self.num_quantizers > limit(cb0.dim, self.training and first.has_commitment_loss):
+            return False
         for layer in self.layers:
             cb = layer._codebook
             if (not layer.channel_last or not cb.is_initialized or cb._stochastic_requested()
@@ -145,6 +152,22 @@ class ResidualVQ(nn.Module):
             ret = (*ret, self.get_codes_from_indices(all_indices))
         return ret
 
+    def _stage_codes(self):
+        """Stacked natural codebooks [1, Q, K, D] ([1, 1, K, D] when shared) and their packed images for the fused launch,
+        rebuilt only when some layer's codes changed (Codebook.codes_state): an inference forward neither re-stacks nor
+        re-packs."""
+        cbs = [self.layers[0]._codebook] if self.shared_codebook else [layer._codebook for layer in self.layers]
+        backend = search.get_backend()
+        key = (tuple(cb.codes_state() for cb in cbs), cbs[0].metric, getattr(backend, "name", None))
+        if self._stage_cache is None or self._stage_cache[0] != key:
+            with torch.no_grad():
+                codes = torch.stack([cb.embeddings.detach()[0] for cb in cbs], dim=0)[None].contiguous()
+                packed = None
+                if getattr(backend, "uses_packed", False) and codes.is_cuda:
+                    packed = backend.pack(codes, cbs[0].metric)
+            self._stage_cache = (key, codes, packed)
+        return self._stage_cache[1], self._stage_cache[2]
+
     def _forward_fused(self, x, freeze_codebook):
         first = self.layers[0]
         cb0 = first._codebook
@@ -155,17 +178,17 @@ class ResidualVQ(nn.Module):
         if flat.dtype != torch.float32:
             flat = flat.float()
         Q = self.num_quantizers
-        if self.shared_codebook:
-            codes = cb0.current_codes()[:, None]  # [1, 1, K, D]
-        else:
-            codes = torch.stack([layer._codebook.current_codes()[0] for layer in self.layers], dim=0)[None]
+        codes, packed = self._stage_codes()  # [1, Q, K, D] ([1, 1, K, D] when shared); fusable stacks are not learnable
         want_loss = training and first.has_commitment_loss
         idx_buf = torch.empty((1, flat.shape[1], Q), dtype=torch.int64, device=flat.device)
         out, idx, sq_err = search.quantize_rows(flat, codes, metric=cb0.metric, ste=training, want_sq_err=want_loss,
-                                                share=self.shared_codebook, idx=idx_buf)
-        losses = torch.zeros((1, Q), dtype=torch.float32, device=flat.device)
+                                                share=self.shared_codebook, idx=idx_buf, packed=packed)
         if want_loss:
-            losses = losses + (sq_err / flat.numel()).to(torch.float32)[None, :] * first.commitment_weight
+            losses = (sq_err / flat.numel()).to(torch.float32)[None, :] * first.commitment_weight
+        elif training:
+            losses = torch.zeros((1, Q), dtype=torch.float32, device=flat.device)
+        else:
+            losses = _cached_zeros(self, "_zero_losses", (1, Q), flat.device)  # no fill kernel per inference forward
 
         if training and not freeze_codebook and cb0.ema_update:
             with torch.no_grad():
@@ -227,6 +250,8 @@ class GroupedResidualVQ(nn.Module):
         self.groups = groups
         self.channel_last = channel_last
         self.rvqs = nn.ModuleList([ResidualVQ(dim=dim // groups, **kwargs) for _ in range(groups)])
+        self._stage_cache = None
+        self._zero_losses = None
 
     @property
     def split_dim(self) -> int:
@@ -276,6 +301,21 @@ class GroupedResidualVQ(nn.Module):
             ret = (*ret, torch.stack(maybe_codes[0]))
         return ret
 
+    def _stage_codes(self):
+        """[G, Q, K, d] natural codebooks + packed images of the one fused launch, rebuilt only when some codes changed."""
+        cbs = [layer._codebook for rvq in self.rvqs for layer in rvq.layers]
+        backend = search.get_backend()
+        key = (tuple(cb.codes_state() for cb in cbs), cbs[0].metric, getattr(backend, "name", None))
+        if self._stage_cache is None or self._stage_cache[0] != key:
+            with torch.no_grad():
+                codes = torch.stack([torch.stack([layer._codebook.embeddings.detach()[0] for layer in rvq.layers], dim=0)
+                                     for rvq in self.rvqs], dim=0).contiguous()
+                packed = None
+                if getattr(backend, "uses_packed", False) and codes.is_cuda:
+                    packed = backend.pack(codes, cbs[0].metric)
+            self._stage_cache = (key, codes, packed)
+        return self._stage_cache[1], self._stage_cache[2]
+
     def _forward_fused(self, x, return_all_codes, freeze_codebook):
         """Groups on the kernel's head axis: x [..., G*d] is searched in place as a [G, rows, d] view."""
         G = self.groups
@@ -289,17 +329,18 @@ class GroupedResidualVQ(nn.Module):
         xc = x if (x.is_contiguous() and x.dtype == torch.float32) else x.contiguous().float()
         rows = xc.numel() // self.dim
         flat = xc.view(rows, G, d).permute(1, 0, 2)
-        codes = torch.stack(
-            [torch.stack([layer._codebook.current_codes()[0] for layer in rvq.layers], dim=0) for rvq in self.rvqs], dim=0
-        )  # [G, Q, K, d]
+        codes, packed = self._stage_codes()  # [G, Q, K, d]
         want_loss = training and first.has_commitment_loss
         q_buf = torch.empty((rows, G, d), dtype=torch.float32, device=xc.device)
         # one launch for all groups and stages; squared errors come back per group (head) and stage
         out, idx, sq_err = search.quantize_rows(flat, codes, metric=cb0.metric, ste=training, want_sq_err=want_loss,
-                                                out=q_buf.permute(1, 0, 2), sq_err_per_head=True)
-        losses = torch.zeros((G, 1, Q), dtype=torch.float32, device=xc.device)
+                                                out=q_buf.permute(1, 0, 2), sq_err_per_head=True, packed=packed)
         if want_loss:
-            losses = losses + (sq_err / (rows * d)).to(torch.float32)[:, None, :] * first.commitment_weight
+            losses = (sq_err / (rows * d)).to(torch.float32)[:, None, :] * first.commitment_weight
+        elif training:
+            losses = torch.zeros((G, 1, Q), dtype=torch.float32, device=xc.device)
+        else:
+            losses = _cached_zeros(self, "_zero_losses", (G, 1, Q), xc.device)
         if training and not freeze_codebook and cb0.ema_update:
             with torch.no_grad():
                 chains = {}

@@ -21,15 +21,26 @@ DOT = native.DOT
 class _NativeBackend:
     name = "hip-gfx950"
     accepts_half_rows = True  # fp16 / bf16 rows are widened in the kernel's prologue (inference launches)
+    uses_packed = True        # callers may hand over a cached packed image of the codebooks (``pack``)
+
+    @staticmethod
+    def max_fused_stages(dim, want_sq_err):
+        """How many residual stages one launch can hold (vq_max_fused_stages); longer stacks run layer by layer."""
+        return native.max_fused_stages(dim, want_sq_err)
+
+    @staticmethod
+    def pack(cb, metric):
+        """cb [..., K, D] contiguous fp32 -> packed images [n, packed_floats] (vq_pack_codebooks_f32)."""
+        return native.pack_codebooks(cb, metric)
 
     @staticmethod
     def quantize(x, cb, *, metric, ste, want_sq_err, share, want_best=False, out=None, idx=None, want_lse=False,
-                 sq_err_per_head=False):
+                 sq_err_per_head=False, packed=None):
         """-> (out, idx, best, sq_err) and, with ``want_lse`` (single stage), a fifth element: the per-row log-sum-exp
         of the similarities from the same sweep (vq_quantize_lse_f32)."""
         r = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, want_best=want_best or want_lse,
                             stages_share_codebook=share, out=out, idx=idx, want_lse=want_lse,
-                            sq_err_per_head=sq_err_per_head)
+                            sq_err_per_head=sq_err_per_head, packed=packed)
         if want_lse:
             return r["out"], r["idx"], r["best"], r["sq_err"], r["lse"]
         return r["out"], r["idx"], r["best"], r["sq_err"]
@@ -101,12 +112,14 @@ class _QuantizeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out_buf, idx_buf, want_lse=False,
-                per_head=False):
+                per_head=False, packed=None):
         extra = {}
         if want_lse:
             extra["want_lse"] = True
         if per_head:
             extra["sq_err_per_head"] = True
+        if packed is not None:
+            extra["packed"] = packed
         res = _backend.quantize(x.detach(), cb.detach(), metric=metric, ste=ste, want_sq_err=want_sq_err, share=share,
                                 out=out_buf, idx=idx_buf, **extra)
         out, idx, best, sq_err = res[:4]
@@ -134,7 +147,7 @@ class _QuantizeFn(torch.autograd.Function):
             # one pass over x / grad_out; no host synchronisation (the torch path below inspects g_err on the host)
             return (fused(x.detach(), cb.detach(), idx, g_out if ctx.ste else None, g_err, ste=ctx.ste, share=ctx.share,
                           **({"sq_err_per_head": True} if ctx.per_head else {})),
-                    None, None, None, None, None, None, None, None, None, None)
+                    None, None, None, None, None, None, None, None, None, None, None)
         if need_x:
             gx = g_out * float(Q) if ctx.ste else torch.zeros_like(x)
         if need_cb:
@@ -158,13 +171,13 @@ class _QuantizeFn(torch.autograd.Function):
                     gcb[:, 0 if ctx.share else q].index_put_((harange.expand_as(i), i), g_out, accumulate=True)
                 quant = r + (c - r) if ctx.ste else c
                 r = r - quant
-        return gx, gcb, None, None, None, None, None, None, None, None, None
+        return gx, gcb, None, None, None, None, None, None, None, None, None, None
 
 
 def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bool = False,
                   want_sq_err: bool = False, share: bool = False, codebook_grad_from_err: bool = False,
                   out: Optional[torch.Tensor] = None, idx: Optional[torch.Tensor] = None, want_lse: bool = False,
-                  sq_err_per_head: bool = False):
+                  sq_err_per_head: bool = False, packed: Optional[torch.Tensor] = None):
     """x [H, M, D] (strided rows allowed), cb [H, Q, K, D] contiguous ([H, 1, K, D] when ``share``; the number
     of stages is then ``idx.shape[-1]``).  ``out`` / ``idx`` may be pre-allocated (strided) destination views.
 
@@ -172,7 +185,11 @@ def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, st
     element: dict(best [H, M, 1], lse [H, M]) -- the winner's distance / similarity and the log-sum-exp of the row's
     similarities, both from the same sweep (what the cross-entropy commitment loss needs).
     ``sq_err_per_head``: sq_err is [H, Q] (one sum per head: GroupedResidualVQ reports a loss per group).
+    ``packed``: a cached packed image of ``cb`` from ``get_backend().pack`` (backends with ``uses_packed``); without it
+    the native backend packs on every call.
     """
+    if packed is not None and not getattr(_backend, "uses_packed", False):
+        packed = None
     if not cb.is_contiguous():
         cb = cb.contiguous()
     # x receives a gradient only through the straight-through output or the squared error: an eval-mode gather
@@ -186,17 +203,18 @@ def quantize_rows(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, st
             x = x.float()  # the reference's x.float() (codebooks.py:354); the native inference launch does it in-kernel
     if needs_grad:
         res = _QuantizeFn.apply(x, cb, metric, ste, want_sq_err, share, codebook_grad_from_err, out, idx, want_lse,
-                                sq_err_per_head)
+                                sq_err_per_head, packed)
         out, idx, sq_err = res[:3]
         if want_lse:
             return out, idx, (sq_err if want_sq_err else None), dict(best=res[3], lse=res[4])
         return out, idx, (sq_err if want_sq_err else None)
+    pk = {"packed": packed} if packed is not None else {}
     if want_lse:
         out, idx, best, sq_err, lse = _backend.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err,
-                                                        share=share, out=out, idx=idx, want_lse=True)
+                                                        share=share, out=out, idx=idx, want_lse=True, **pk)
         return out, idx, sq_err, dict(best=best, lse=lse)
     out, idx, _best, sq_err = _backend.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, share=share,
-                                                out=out, idx=idx,
+                                                out=out, idx=idx, **pk,
                                                 **({"sq_err_per_head": True} if sq_err_per_head else {}))
     return out, idx, sq_err
 

@@ -4,9 +4,14 @@ Rank g of the process group holds rows ``[g*K/G, (g+1)*K/G)`` of a codebook that
 
     1. every rank searches ITS shard for all rows (native kernel) and emits one packed signed 64-bit key per
        row: (order image of the winning value) << 32 | (global code index);
-    2. ONE collective: ``all_reduce(keys, op=MIN)`` (RCCL ``ncclMin`` on int64 over xGMI; 8 bytes per row).
+    2. ONE collective, two interchangeable forms (``reduction=``):
+       ``"all_reduce"``  ``all_reduce(keys, op=MIN)`` (RCCL ``ncclMin`` on int64; 8 bytes per row; a ring on xGMI, i.e.
+                         2 (G - 1) latency-bound steps over one ~153 GB/s link each);
+       ``"all_gather"``  every rank sends its M keys to every other rank in ONE hop over all 7 xGMI links
+                         (``all_gather_into_tensor``, 8 (G - 1) M bytes received per rank) and takes the min over the G
+                         candidates locally -- the better shape while M * 8 B is latency-bound.
        Equal distances resolve to the lowest GLOBAL index -- the reference's first-argmax semantics
-       (utils/general.py:128) -- because the index sits in the low word;
+       (utils/general.py:128) -- because the index sits in the low word, in either form;
     3. finalize: decode, gather ``codebook[idx]``.  The gather table is either a replicated full copy
        (``gather="replicated"``: 128 MiB at K=65536, D=512 is nothing in 288 GB) or stays sharded
        (``gather="owner"``: the owner rank contributes the row, everybody else zeros, and a SUM all-reduce
@@ -60,7 +65,9 @@ class ShardedCodebookSearch:
     """
 
     def __init__(self, shard: torch.Tensor, *, use_cosine_sim: bool = False, group=None,
-                 full_codebook: Optional[torch.Tensor] = None, ops=None):
+                 full_codebook: Optional[torch.Tensor] = None, ops=None, reduction: str = "all_reduce"):
+        assert reduction in ("all_reduce", "all_gather"), reduction
+        self.reduction = reduction
         self.group = group
         self.metric = native.DOT if use_cosine_sim else native.EUCLID
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -78,8 +85,17 @@ class ShardedCodebookSearch:
             keys = self.ops.local_keys(x.float(), self.shard, self.metric, self.rank * self.k_local, self.packed)
         else:
             keys = self.ops.local_keys(x.float(), self.shard, self.metric, self.rank * self.k_local)
-        if self.world > 1:
-            dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
+        return self.reduce_keys(keys)
+
+    def reduce_keys(self, keys: torch.Tensor) -> torch.Tensor:
+        """keys [M] int64 of this rank's shard -> the element-wise minimum over the ranks (identical everywhere)."""
+        if self.world == 1:
+            return keys
+        if self.reduction == "all_gather":
+            every = torch.empty((self.world, keys.shape[0]), dtype=torch.int64, device=keys.device)
+            dist.all_gather_into_tensor(every, keys.contiguous(), group=self.group)
+            return every.amin(dim=0)
+        dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
         return keys
 
     def quantize_local_rows(self, x_local: torch.Tensor, *, ste: bool = False, want_sq_err: bool = False):
