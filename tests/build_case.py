@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from gen import CB_SEED, l2norm, make_codebook, make_rvq_codebooks, make_x
+from gen import CB_SEED, l2norm, make_codebook, make_rvq_codebooks, make_x, seeded_projection_
 
 
 def make_mask(b, n):
@@ -63,7 +63,9 @@ def build(case, arrays=None, device="cpu"):
         with torch.no_grad():
             mod._codebook.embeddings.copy_(cb)
             mod._codebook.embed_avg.copy_(cb)
-            if mod.has_projections:
+            if mod.has_projections and case.get("seeded_proj", False):
+                seeded_projection_(mod)
+            elif mod.has_projections:
                 assert arrays is not None
                 mod.project_in.weight.copy_(torch.from_numpy(arrays["proj_in_w"]))
                 mod.project_in.bias.copy_(torch.from_numpy(arrays["proj_in_b"]))

@@ -41,9 +41,26 @@ def compare(case, arrays, meta, outputs, x, cb, mod=None):
         # near-tie heavy class (or ATen's small-size direct kernel): report, and require the rest to agree
         frac = n_mismatch / got_idx.size
         assert frac < 0.02, f"{n_mismatch} of {got_idx.size} indices differ"
-        if n_mismatch and case["kind"] == "vq" and case.get("heads", 1) == 1 and case.get("channel_last", True):
-            certify_near_ties(x.detach().cpu().reshape(-1, x.shape[-1]).numpy(), cb[0].cpu().numpy(),
-                              got_idx.reshape(-1), ref_idx.reshape(-1), case.get("use_cosine_sim", False))
+        if n_mismatch and case["kind"] == "vq":
+            # every mismatch must be a certified near-tie, head by head, on the rows the search actually saw (channel-last,
+            # after the module's own input projection and row transform)
+            heads = case.get("heads", 1)
+            xs = x.detach().cpu()
+            if not case.get("channel_last", True):
+                xs = xs.movedim(1, -1)
+            xs = xs.reshape(xs.shape[0], -1, xs.shape[-1])
+            if mod is not None:
+                with torch.no_grad():
+                    dev = mod._codebook.embeddings.device
+                    xs = mod.project_in(xs.to(dev)).cpu() if mod.has_projections else xs
+                    xs = mod._codebook.transform_input(xs.reshape(*xs.shape[:-1], heads, -1)).reshape(xs.shape)
+            d = xs.shape[-1] // heads
+            rows = xs.reshape(-1, heads, d).numpy()
+            gi, ri = got_idx.reshape(-1, heads), ref_idx.reshape(-1, heads)
+            cbn = cb.cpu().numpy()
+            for hd in range(heads):
+                certify_near_ties(rows[:, hd], cbn[hd if cbn.shape[0] > 1 else 0], gi[:, hd], ri[:, hd],
+                                  case.get("use_cosine_sim", False))
     else:
         assert n_mismatch == 0, f"{n_mismatch} of {got_idx.size} indices differ from the reference"
     assert loss.shape == torch.Size(arrays["loss"].shape), (loss.shape, arrays["loss"].shape)

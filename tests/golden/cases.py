@@ -36,6 +36,12 @@ CASES = [
     # --- cfg3: multi-head, per-head codebooks, K=8192, dim=512 -> 8 x 64 ---------------------------
     _vq("cfg3a_S", 512, 8192, (2, 128, 512), "S", heads=8, codebook_dim=64, separate_codebook_per_head=True),
     _vq("cfg3a_R", 512, 8192, (2, 128, 512), "R", heads=8, codebook_dim=64, separate_codebook_per_head=True),
+    # --- cfg3b: the other reading of BASELINE configs[2]: per-head dim 512, i.e. Linear 512 -> 4096 -> 512
+    #     projections around 8 heads x K=8192 x D=512 (M reduced).  The projection weights are seeded on both sides
+    #     (seeded_proj: 16 MB of Linear weights do not belong in a fixture); the reference computes them with MKL, the build
+    #     with the device GEMM, so only the separated class asks for 100 % equal indices.
+    _vq("cfg3b_S", 512, 8192, (1, 64, 512), "S", heads=8, codebook_dim=512, separate_codebook_per_head=True, seeded_proj=True),
+    _vq("cfg3b_R", 512, 8192, (1, 64, 512), "R", heads=8, codebook_dim=512, separate_codebook_per_head=True, seeded_proj=True),
     _vq("mh_shared_S", 256, 512, (2, 64, 256), "S", heads=4, codebook_dim=64, separate_codebook_per_head=False),
     _vq("mh_shared_S_train", 256, 512, (2, 64, 256), "S", heads=4, codebook_dim=64,
         separate_codebook_per_head=False, training=True),
@@ -90,6 +96,15 @@ CASES = [
         cb_extra=dict(initialization_by_kmeans=True, threshold_ema_dead_code=0, kmeans_iter=5)),
     _vq("dead_code_expiry_S", 32, 300, (4, 64, 32), "S", training=True, freeze_codebook=False, cpu_only=True, forward_seed=123,
         cb_extra=dict(threshold_ema_dead_code=2)),
+    # cosine k-means on rows that are NOT normalised by the module (the first centroids and the cluster means are
+    # raw rows, only the new centroids are normalised, utils/kmeans.py:82-118)
+    _vq("kmeans_init_cos_raw_S", 32, 16, (4, 64, 32), "S", training=True, freeze_codebook=False, cpu_only=True, forward_seed=123,
+        use_cosine_sim=True, cb_extra=dict(initialization_by_kmeans=True, threshold_ema_dead_code=0, kmeans_iter=5)),
+    # heads that SHARE a codebook: re-seeding draws row indices from the reference's "(b h) n" flattening
+    _vq("dead_code_expiry_mh_shared_S", 32, 300, (4, 64, 32), "S", training=True, freeze_codebook=False, cpu_only=True,
+        forward_seed=123, heads=2, codebook_dim=16, cb_extra=dict(threshold_ema_dead_code=2)),
+    _vq("kmeans_init_mh_shared_S", 32, 16, (4, 64, 32), "S", training=True, freeze_codebook=False, cpu_only=True, forward_seed=123,
+        heads=2, codebook_dim=16, cb_extra=dict(initialization_by_kmeans=True, threshold_ema_dead_code=0, kmeans_iter=5)),
     dict(name="grvq_train", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=True),
     dict(name="grvq_ema", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=True,
          freeze_codebook=False, cb_extra=dict(threshold_ema_dead_code=0)),

@@ -68,3 +68,15 @@ def checksum(t: torch.Tensor):
 
 def l2norm(t: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.normalize(t, p=2, dim=-1)
+
+
+def seeded_projection_(mod, seed: int = 5150) -> None:
+    """Overwrite the Linear projections of a VectorQuantize-like module (``project_in`` / ``project_out``, reference and
+    drop-in alike) with seeded weights, so that large projections need not be stored in a fixture."""
+    g = _gen(seed)
+    lin_in = mod.project_in if isinstance(mod.project_in, torch.nn.Linear) else mod.project_in[0]
+    with torch.no_grad():
+        for lin in (lin_in, mod.project_out):
+            fan_in = lin.weight.shape[1]
+            lin.weight.copy_(torch.randn(tuple(lin.weight.shape), generator=g) / math.sqrt(fan_in))
+            lin.bias.copy_(torch.randn(tuple(lin.bias.shape), generator=g) * 0.1)

@@ -25,7 +25,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 from cases import CASES, LOSS_CASES  # noqa: E402
-from gen import CB_SEED, checksum, l2norm, make_codebook, make_rvq_codebooks, make_x  # noqa: E402
+from gen import CB_SEED, checksum, l2norm, make_codebook, make_rvq_codebooks, make_x, seeded_projection_  # noqa: E402
 
 
 def _import_reference():
@@ -84,6 +84,8 @@ def run_vq(ref, ref_cb, c):
     with torch.no_grad():
         mod._codebook.embeddings.copy_(cb)
         mod._codebook.embed_avg.copy_(cb)
+    if c.get("seeded_proj", False):
+        seeded_projection_(mod)
     x = make_x(c["x_shape"], c["cls"])
     stash = {}
 
@@ -118,7 +120,7 @@ def run_vq(ref, ref_cb, c):
     arrays["q_rows"], arrays["q_vals"] = rows, vals
     if q.numel() <= 1 << 16:
         arrays["q_full"] = q.detach().numpy().copy()
-    if mod.has_projections:
+    if mod.has_projections and not c.get("seeded_proj", False):
         lin_in = mod.project_in if isinstance(mod.project_in, torch.nn.Linear) else mod.project_in[0]
         arrays["proj_in_w"] = lin_in.weight.detach().numpy().copy()
         arrays["proj_in_b"] = lin_in.bias.detach().numpy().copy()

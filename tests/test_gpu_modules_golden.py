@@ -37,6 +37,35 @@ def test_module_matches_reference_golden_on_gpu(case):
     compare(case, arrays, meta, outputs, x, cb, mod)
 
 
+SEEDED_CASES = [c for c in CASES if c.get("cpu_only", False)]
+
+
+@pytest.mark.parametrize("case", SEEDED_CASES, ids=[c["name"] for c in SEEDED_CASES])
+def test_kmeans_seeding_and_dead_code_reseeding_match_reference_golden_on_gpu(case, monkeypatch):
+    """SURVEY 8f rank 2 on the device: k-means seeding (Lloyd iterations = native search + native
+    vq_ema_accumulate_f32) and dead-code re-seeding against the reference's state.  The goldens were produced with torch's
+    CPU generator (torch.manual_seed(forward_seed) before the forward), whose stream a device generator cannot reproduce:
+    the row INDICES are drawn with the CPU generator exactly as the CPU-pinned test draws them and are then used to index
+    the rows on the GPU, so everything after the draw -- assignment, per-cluster sums, the codebook writes -- is the
+    product's device path."""
+    from vector_quantization import codebook as codebook_mod
+
+    def pick_rows_with_cpu_draws(rows, count):
+        n = rows.shape[0]
+        sel = torch.randperm(n)[:count] if n >= count else torch.randint(0, n, (count,))
+        return rows[sel.to(rows.device)]
+
+    monkeypatch.setattr(codebook_mod, "_pick_rows", pick_rows_with_cpu_draws)
+    arrays, meta = load_golden(case["name"])
+    mod, x, kwargs, cb = build(case, arrays, device="cuda:0")
+    torch.manual_seed(case["forward_seed"])
+    with torch.no_grad():
+        outputs = mod(x, **kwargs)
+    torch.cuda.synchronize()
+    assert mod._codebook.embeddings.is_cuda
+    compare(case, arrays, meta, outputs, x, cb, mod)
+
+
 @pytest.mark.parametrize("case", LOSS_CASES, ids=[c["name"] for c in LOSS_CASES])
 def test_similarity_consuming_losses_match_reference_golden_on_gpu(case):
     """SURVEY 8f rank 3 on the native kernels (vq_softmax_stats_f32 forward, vq_similarities_f32 chunks backward)."""

@@ -303,12 +303,14 @@ class Codebook(nn.Module):
 
     # ------------------------------------------------------------------ training-state bookkeeping
     @torch.no_grad()
-    def ema_step(self, flat: torch.Tensor, idx: torch.Tensor, flat_mask=None):
+    def ema_step(self, flat: torch.Tensor, idx: torch.Tensor, flat_mask=None, sample_pool=None):
         """Exponential-moving-average codebook update + dead-code re-seeding (codebooks.py:399-426),
-        expressed with index arithmetic instead of the reference's [h, M, K] one-hot products."""
+        expressed with index arithmetic instead of the reference's [h, M, K] one-hot products.
+        ``sample_pool``: the rows re-seeding draws from, in the REFERENCE's row order (a tensor or a callable returning it;
+        default ``flat``) -- the draw is an index into them, so the order matters (shared codebook with several heads)."""
         hits, sums = search.get_backend().ema_accumulate(flat, idx, self.codebook_size, flat_mask)
         self.ema_apply(hits, sums)
-        self.reseed_dead_codes(flat)
+        self.reseed_dead_codes(sample_pool if sample_pool is not None else flat)
 
     @torch.no_grad()
     def ema_apply(self, hits: torch.Tensor, sums: torch.Tensor):
@@ -362,7 +364,10 @@ class Codebook(nn.Module):
         k = self.codebook_size
         iters = (self.kmeans_params or {}).get("iter", 10)
         sync = self.use_ddp and (self.kmeans_params or {}).get("sync", True)
-        data = _unit_rows(flat) if self.use_cosine_sim else flat
+        # utils/kmeans.py:82-118: the first centroids are RAW sampled rows and the per-cluster means are means of the RAW rows;
+        # with the cosine similarity only the new centroids are L2-normalised (the rows are not, unless the module's
+        # transform_input already did it)
+        data = flat
         pick = _pick_rows_all_ranks if (sync and dist.is_available() and dist.is_initialized()) else _pick_rows
         means = torch.stack([pick(data[i], k) for i in range(h)])
         counts = torch.zeros((h, k), dtype=flat.dtype, device=flat.device)

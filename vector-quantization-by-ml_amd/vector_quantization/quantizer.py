@@ -204,8 +204,19 @@ class VectorQuantize(nn.Module):
             per_row = mask.reshape(rows)
             flat_mask = per_head_rows(per_row[:, None].expand(rows, heads))
 
+        def sampling_rows():
+            """The rows as the reference orders them, for steps that pick rows by a random INDEX (k-means seeding, dead-code
+            re-seeding): heads that share one codebook are flattened "(b h) n" there (vector_quantize_pytorch.py:217-219), while
+            the search above runs on the (b n h) order of the buffer (the search itself is order-independent)."""
+            if self.separate_codebook_per_head or heads == 1:
+                return flat.detach()
+            return x4.detach().view(batch, n, heads, head_dim).transpose(1, 2).reshape(1, rows * heads, head_dim)
+
         if not cb.is_initialized:
-            cb.seed_with_kmeans(flat.detach(), flat_mask)
+            seed_mask = flat_mask
+            if flat_mask is not None and not (self.separate_codebook_per_head or heads == 1):
+                seed_mask = mask.reshape(batch, 1, n).expand(batch, heads, n).reshape(1, rows * heads)
+            cb.seed_with_kmeans(sampling_rows(), seed_mask)
             cb.is_initialized = True
 
         if training or return_loss:
@@ -228,7 +239,7 @@ class VectorQuantize(nn.Module):
             self.in_place_codebook_optimizer.step()
             self.in_place_codebook_optimizer.zero_grad()
             if will_update:  # the reference's first Codebook.forward already ran its EMA step
-                cb.ema_step(flat.detach(), first_idx, flat_mask)
+                cb.ema_step(flat.detach(), first_idx, flat_mask, sample_pool=sampling_rows)
         # cross-entropy commitment: the search sweep also emits the row's log-sum-exp (no second sweep for the loss)
         ce_from_search = training and want_loss and use_ce
         ce_stats = None
@@ -283,7 +294,7 @@ class VectorQuantize(nn.Module):
             loss = loss + commit_loss * self.commitment_weight
 
         if will_update:
-            cb.ema_step(flat.detach(), idx, flat_mask)
+            cb.ema_step(flat.detach(), idx, flat_mask, sample_pool=sampling_rows)
 
         if return_loss:
             # the reference returns here, before heads are merged / projected back (vector_quantize_pytorch.py:298)
