@@ -67,6 +67,23 @@ class OracleBackend:
 
 
     @staticmethod
+    def shard_keys(x, cb, *, metric, idx_offset, packed=None):
+        """CPU stand-in for the shard-local search: packed (value, idx_offset + index) keys [H, M]."""
+        xn = np.ascontiguousarray(x.detach().cpu().numpy(), dtype=np.float32)
+        cbn = np.ascontiguousarray(cb.detach().cpu().numpy(), dtype=np.float32)
+        keys = []
+        for h in range(xn.shape[0]):
+            i, b = vq_oracle.nearest(xn[h], cbn[h], metric)
+            keys.append(vq_oracle.pack_key(b, i + idx_offset, metric))
+        return torch.from_numpy(np.stack(keys))
+
+    @staticmethod
+    def finalize_keys(x, table, keys, *, metric):
+        _best, idx = vq_oracle.unpack_key(keys.numpy(), metric)
+        idx = torch.from_numpy(idx)
+        return table[torch.arange(table.shape[0])[:, None], idx], idx
+
+    @staticmethod
     def ema_accumulate(x, idx, k, mask=None):
         """counts / sums of the rows assigned to each code, with plain index arithmetic (reference: one-hot products)."""
         h, m, d = x.shape

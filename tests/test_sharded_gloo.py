@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, metric_dot, gather, K, D, M, out_dir):
+def _worker(rank, world, port, metric_dot, gather, K, D, M, out_dir, reduction="all_reduce"):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,7 +41,7 @@ def _worker(rank, world, port, metric_dot, gather, K, D, M, out_dir):
     kl = K // world
     shard = full[rank * kl:(rank + 1) * kl]
     s = ShardedCodebookSearch(shard, use_cosine_sim=metric_dot, full_codebook=full if gather != "owner" else None,
-                              ops=OracleShardOps)
+                              ops=OracleShardOps, reduction=reduction)
     out, idx, best, sq = s(x, want_sq_err=True)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), out=out.numpy(), idx=idx.numpy(),
              best=(best.numpy() if best is not None else np.zeros(1, np.float32)), sq=sq.numpy())
@@ -49,14 +49,16 @@ def _worker(rank, world, port, metric_dot, gather, K, D, M, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,metric_dot,gather", [(2, False, "replicated"), (2, True, "replicated"),
-                                                     (2, False, "owner"), (4, False, "dup")])
-def test_sharded_equals_full(tmp_path, oracle, world, metric_dot, gather):
+@pytest.mark.parametrize("world,metric_dot,gather,reduction", [
+    (2, False, "replicated", "all_reduce"), (2, True, "replicated", "all_reduce"), (2, False, "owner", "all_reduce"),
+    (4, False, "dup", "all_reduce"), (2, True, "replicated", "all_gather"), (3, False, "owner", "all_gather"),
+    (8, False, "dup", "all_gather"), (8, False, "replicated", "all_reduce")])
+def test_sharded_equals_full(tmp_path, oracle, world, metric_dot, gather, reduction):
     from gen import make_codebook, make_x
 
-    K, D, M = 512, 64, 300
+    K, D, M = (512, 64, 300) if world != 3 else (384, 64, 300)
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, metric_dot, gather, K, D, M, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, metric_dot, gather, K, D, M, str(tmp_path), reduction), nprocs=world, join=True)
     cls = "Gdup" if gather == "dup" else "S"
     full = make_codebook(1, K, D, cls)[0].numpy()
     x = make_x((M, D), cls).numpy()

@@ -10,6 +10,7 @@ hand-written HIP for gfx950 behind the C ABI in ``include/vq_mi355x.h``; there i
 The reference's other quantizer families (FSQ, LFQ, latent quantization and their residual variants) never
 touch the codebook search and are not part of this build.
 """
+from . import ops  # noqa: F401  (registers torch.ops.vq_mi355x.*)
 from .codebook import Codebook
 from .graphs import GraphedForward
 from .params import AffineParameters, CodebookParams, GumbelParams, KmeansParameters

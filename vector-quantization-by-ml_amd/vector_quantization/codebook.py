@@ -191,7 +191,11 @@ class Codebook(nn.Module):
         """Packed image [h, packed_floats] of the codes for the native search (None for backends without one), cached:
         an inference forward does not re-pack an unchanged codebook (13 us at K=1024 D=256, 121 us at K=65536 D=512)."""
         backend = search.get_backend()
-        if not getattr(backend, "uses_packed", False) or not self.embeddings.is_cuda:
+        if not getattr(backend, "uses_packed", False):
+            return None
+        if torch.compiler.is_compiling():  # traced: the pack is a node of the graph (no identity-keyed cache inside a trace)
+            return backend.pack(self.embeddings.detach().contiguous(), self.metric)
+        if not self.embeddings.is_cuda:
             return None
         key = (self.codes_state(), self.metric)
         if self._packed_key != key:
@@ -322,6 +326,21 @@ class Codebook(nn.Module):
         search.get_backend().ema_update(self.cluster_size.data, self.embed_avg.data, self.embeddings.data, hits, sums,
                                         decay=self.decay, eps=self.eps_for_smoothing,
                                         l2norm=self.weights_regularization is _unit_rows)
+        self.invalidate_packed()
+
+    @torch.no_grad()
+    def ema_apply_shard(self, hits: torch.Tensor, sums: torch.Tensor, group, k_total: int):
+        """EMA step of ONE SHARD of a codebook that is sharded over ``group`` (codebooks.py:410-425 for the codes this rank
+        owns).  The statistics of a code live on its owner only, so they need no reduction; the Laplace smoothing
+        normalises with the cluster sizes of the WHOLE codebook, so the per-shard totals are all-reduced."""
+        w = 1.0 - self.decay
+        self.cluster_size.data.lerp_(hits, w)
+        self.embed_avg.data.lerp_(sums, w)
+        total = self.cluster_size.data.sum(dim=-1, keepdim=True)
+        dist.all_reduce(total, group=group)
+        smoothed = (self.cluster_size.data + self.eps_for_smoothing) / (total + k_total * self.eps_for_smoothing) * total
+        fresh = self.weights_regularization(self.embed_avg.data / smoothed[..., None])
+        self.embeddings.data.copy_(fresh)
         self.invalidate_packed()
 
     @torch.no_grad()

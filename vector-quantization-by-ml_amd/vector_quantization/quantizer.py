@@ -30,6 +30,8 @@ LossBreakdown = namedtuple(
 def _cached_zeros(module, attr: str, shape, device) -> torch.Tensor:
     """A persistent all-zero fp32 tensor for the loss an inference forward returns (the reference allocates one per call,
     i.e. a fill kernel per forward).  Re-created if the caller modified the previous one in place."""
+    if torch.compiler.is_compiling():
+        return torch.zeros(shape, dtype=torch.float32, device=device)
     entry = getattr(module, attr, None)
     if (entry is None or entry[0].device != device or tuple(entry[0].shape) != tuple(shape)
             or entry[0]._version != entry[1]):
@@ -63,7 +65,18 @@ class VectorQuantize(nn.Module):
         sync_codebook=None,
         in_place_codebook_optimizer: Optional[Callable] = None,
         sync_update_v=0.0,
+        codebook_shard_group=None,
+        codebook_shard_reduction: str = "all_gather",
+        codebook_shard_gather: str = "owner",
     ):
+        """Arguments up to ``sync_update_v`` are the reference's (vector_quantize_pytorch.py:39-60).  New, keyword-only in
+        spirit: ``codebook_shard_group`` (a process group, or True for the default group) shards the codebook's K codes over
+        the ranks -- ``codebook_params.codebook_size`` stays the GLOBAL K, ``_codebook`` (and the checkpoint) hold this
+        rank's ``[K / G, D]`` rows, every rank sees the same tokens, and the forward is shard-local search -> packed
+        (distance, index) keys -> one collective (``codebook_shard_reduction``: "all_gather" + local min, one hop over all
+        xGMI links, or "all_reduce" with MIN) -> gather of the winning rows from their owners
+        (``codebook_shard_gather``: "owner" = SUM all-reduce of the owners' rows, no replicated table; "replicated" = an
+        all-gathered full table cached on every rank).  BASELINE configs[4] / north_star."""
         super().__init__()
         self.dim = dim
         self.heads = heads
@@ -100,6 +113,31 @@ class VectorQuantize(nn.Module):
             "learnable codebook must be turned on"
         )
         self.sync_update_v = sync_update_v
+
+        # ---- codebook sharded over the ranks of a process group (new capability: SURVEY 8e, BASELINE configs[4])
+        self.shard_group = None
+        self.shard_world, self.shard_rank = 1, 0
+        self.codebook_size = codebook_params.codebook_size  # global K
+        if codebook_shard_group is not None and codebook_shard_group is not False:
+            assert dist.is_available() and dist.is_initialized(), "codebook_shard_group needs an initialised process group"
+            assert codebook_shard_reduction in ("all_gather", "all_reduce") and codebook_shard_gather in ("owner", "replicated")
+            self.shard_group = None if codebook_shard_group is True else codebook_shard_group
+            self.shard_world = dist.get_world_size(self.shard_group)
+            self.shard_rank = dist.get_rank(self.shard_group)
+            unsupported = dict(commitment_use_cross_entropy_loss=commitment_use_cross_entropy_loss,
+                               orthogonal_reg=orthogonal_reg_weight > 0.0, diversity_loss=codebook_diversity_loss_weight > 0.0,
+                               in_place_codebook_optimizer=in_place_codebook_optimizer is not None,
+                               learnable_codebook=codebook_params.learnable_codebook,
+                               initialization_by_kmeans=codebook_params.initialization_by_kmeans)
+            bad = [k for k, v in unsupported.items() if v]
+            if bad:
+                raise NotImplementedError(f"a sharded codebook supports the search / quantize step / EMA update only, not {bad}")
+            assert codebook_params.codebook_size % self.shard_world == 0, "codebook_size must divide evenly over the shard group"
+            codebook_params = replace(codebook_params, codebook_size=codebook_params.codebook_size // self.shard_world)
+            sync_codebook = False  # every rank owns different codes: nothing to average between ranks
+        self.shard_reduction = codebook_shard_reduction
+        self.shard_gather = codebook_shard_gather
+        self._shard_table = None
 
         if sync_codebook is None:
             sync_codebook = _world_is_distributed()
@@ -150,6 +188,67 @@ class VectorQuantize(nn.Module):
         if not self.channel_last:
             return self.project_out(codes.movedim(1, -1)).movedim(-1, 1)
         return self.project_out(codes)
+
+    # ------------------------------------------------------------------ codebook sharded over a process group
+    def _reduce_keys(self, keys):
+        """Element-wise MIN of the packed keys over the shard group (identical result on every rank)."""
+        if self.shard_reduction == "all_gather":
+            every = torch.empty((self.shard_world * keys.numel(),), dtype=torch.int64, device=keys.device)
+            dist.all_gather_into_tensor(every, keys.reshape(-1), group=self.shard_group)
+            return every.view(self.shard_world, *keys.shape).amin(dim=0)
+        dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.shard_group)
+        return keys
+
+    def gather_table(self):
+        """The full natural codebook [h, K, D], all-gathered from the shards and cached until this rank's shard changes
+        (the ranks change their shards in lockstep: EMA steps and checkpoint loads are collective)."""
+        cb = self._codebook
+        key = cb.codes_state()
+        if self._shard_table is None or self._shard_table[0] != key:
+            local = cb.embeddings.detach().contiguous()  # [h, K/G, D]
+            parts = torch.empty((self.shard_world * local.numel(),), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(parts, local.reshape(-1), group=self.shard_group)
+            parts = parts.view(self.shard_world, *local.shape)
+            self._shard_table = (key, parts.permute(1, 0, 2, 3).reshape(local.shape[0], -1, local.shape[-1]).contiguous())
+        return self._shard_table[1]
+
+    @torch.no_grad()
+    def _sharded_search(self, flat, out_view, idx_view):
+        """flat [h, M, D] (the same rows on every rank) -> (quantized rows [h, M, D], GLOBAL indices [h, M])."""
+        from . import search
+
+        cb, backend = self._codebook, search.get_backend()
+        k_local = cb.codebook_size
+        x = flat if flat.dtype == torch.float32 else flat.float()
+        keys = backend.shard_keys(x, cb.embeddings.detach(), metric=cb.metric, idx_offset=self.shard_rank * k_local,
+                                  packed=cb.packed_codes())
+        keys = self._reduce_keys(keys)
+        if self.shard_gather == "replicated":
+            quant, idx = backend.finalize_keys(x, self.gather_table(), keys, metric=cb.metric)
+        else:
+            idx = keys & 0xFFFFFFFF
+            local = idx - self.shard_rank * k_local
+            mine = (local >= 0) & (local < k_local)
+            h = x.shape[0]
+            rows = cb.embeddings.detach()[torch.arange(h, device=x.device)[:, None], local.clamp(0, k_local - 1)]
+            quant = torch.where(mine[..., None], rows, torch.zeros((), dtype=rows.dtype, device=rows.device))
+            dist.all_reduce(quant, group=self.shard_group)  # exactly one owner per row: x + 0 + ... is exact
+        out_view.copy_(quant)
+        idx_view.copy_(idx[..., None])
+        return out_view, idx
+
+    @torch.no_grad()
+    def _sharded_ema_step(self, flat, idx):
+        """EMA statistics of the codes THIS rank owns (rows whose winner lives here), then the shard's update."""
+        from . import search
+
+        cb = self._codebook
+        k_local = cb.codebook_size
+        local = idx - self.shard_rank * k_local
+        mine = (local >= 0) & (local < k_local)
+        hits, sums = search.get_backend().ema_accumulate(flat.float(), local.clamp(0, k_local - 1).contiguous(), k_local, mine)
+        cb.ema_apply_shard(hits, sums, self.shard_group, self.codebook_size)
+        cb.reseed_dead_codes(flat)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, indices=None, mask=None, freeze_codebook=False, return_loss_breakdown=False):
@@ -243,7 +342,19 @@ class VectorQuantize(nn.Module):
         # cross-entropy commitment: the search sweep also emits the row's log-sum-exp (no second sweep for the loss)
         ce_from_search = training and want_loss and use_ce
         ce_stats = None
-        if mask is None:
+        if self.shard_world > 1:
+            assert mask is None and not return_loss, "a sharded codebook supports neither masks nor given indices"
+            quant, idx = self._sharded_search(flat.detach(), out_view, idx_view)
+            if training:
+                out = flat + (quant - flat).detach()  # straight-through (vector_quantize_pytorch.py:273)
+                if want_sq_err:
+                    commit_loss = ((quant.detach() - flat) ** 2).mean()
+                if will_update:
+                    self._sharded_ema_step(flat.detach(), idx)
+                    will_update = False
+            else:
+                out = quant
+        elif mask is None:
             # the one native launch: search + gather + straight-through + squared error
             out, idx, sq_err, *rest = cb.quantize_flat(flat, ste=training, want_sq_err=want_sq_err,
                                                        codebook_grad_from_err=cb_grad_from_err, out=out_view,

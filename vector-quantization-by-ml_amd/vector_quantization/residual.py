@@ -158,6 +158,9 @@ class ResidualVQ(nn.Module):
         re-packs."""
         cbs = [self.layers[0]._codebook] if self.shared_codebook else [layer._codebook for layer in self.layers]
         backend = search.get_backend()
+        if torch.compiler.is_compiling():  # traced: stack and pack are nodes of the graph
+            codes = torch.stack([cb.embeddings.detach()[0] for cb in cbs], dim=0)[None].contiguous()
+            return codes, (backend.pack(codes, cbs[0].metric) if getattr(backend, "uses_packed", False) else None)
         key = (tuple(cb.codes_state() for cb in cbs), cbs[0].metric, getattr(backend, "name", None))
         if self._stage_cache is None or self._stage_cache[0] != key:
             with torch.no_grad():

@@ -24,6 +24,7 @@ class _NativeBackend:
     uses_packed = True        # callers may hand over a cached packed image of the codebooks (``pack``)
 
     @staticmethod
+    @torch.compiler.assume_constant_result  # host arithmetic in the library: a constant of (dim, want_sq_err) for a trace
     def max_fused_stages(dim, want_sq_err):
         """How many residual stages one launch can hold (vq_max_fused_stages); longer stacks run layer by layer."""
         return native.max_fused_stages(dim, want_sq_err)
@@ -31,6 +32,10 @@ class _NativeBackend:
     @staticmethod
     def pack(cb, metric):
         """cb [..., K, D] contiguous fp32 -> packed images [n, packed_floats] (vq_pack_codebooks_f32)."""
+        if torch.compiler.is_compiling():
+            from . import ops
+
+            return ops.pack(cb, metric)
         return native.pack_codebooks(cb, metric)
 
     @staticmethod
@@ -38,12 +43,40 @@ class _NativeBackend:
                  sq_err_per_head=False, packed=None):
         """-> (out, idx, best, sq_err) and, with ``want_lse`` (single stage), a fifth element: the per-row log-sum-exp
         of the similarities from the same sweep (vq_quantize_lse_f32)."""
+        if torch.compiler.is_compiling() and not (want_best or want_lse):
+            # being traced by torch.compile / export: go through the registered op (ops.py) so the graph does not break here
+            from . import ops
+
+            H, M, D = x.shape
+            Q = idx.shape[-1] if idx is not None else (1 if share else cb.shape[1])
+            if out is None:
+                out = torch.empty((H, M, D), dtype=torch.float32, device=x.device)
+            if idx is None:
+                idx = torch.empty((H, M, Q), dtype=torch.int64, device=x.device)
+            sq_err = ops.quantize_into(x, cb, packed, out, idx, metric, ste, want_sq_err, share, sq_err_per_head)
+            return out, idx, None, (sq_err if want_sq_err else None)
         r = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=want_sq_err, want_best=want_best or want_lse,
                             stages_share_codebook=share, out=out, idx=idx, want_lse=want_lse,
                             sq_err_per_head=sq_err_per_head, packed=packed)
         if want_lse:
             return r["out"], r["idx"], r["best"], r["sq_err"], r["lse"]
         return r["out"], r["idx"], r["best"], r["sq_err"]
+
+    @staticmethod
+    def shard_keys(x, cb, *, metric, idx_offset, packed=None):
+        """Search ONE SHARD of a codebook: x [H, M, D], cb [H, K_local, D] -> packed signed 64-bit keys [H, M]
+        ((order image of the winning value) << 32 | idx_offset + local index; vq_keys_init + vq_search_keys_f32).
+        The element-wise MIN of the shards' keys is the whole codebook's winner, lowest index on ties."""
+        keys = torch.empty((x.shape[0], x.shape[1]), dtype=torch.int64, device=x.device)
+        native.keys_init(keys)
+        native.search_keys(x, cb, keys, metric=metric, idx_offset=idx_offset, packed=packed)
+        return keys
+
+    @staticmethod
+    def finalize_keys(x, table, keys, *, metric):
+        """Reduced keys + a FULL natural table [H, K, D] -> (quantized rows [H, M, D], idx [H, M]) (vq_finalize_keys_f32)."""
+        r = native.finalize_keys(x, table, keys, metric=metric)
+        return r["out"], r["idx"]
 
     @staticmethod
     def similarities(x, cb, *, metric, out=None):

@@ -92,9 +92,9 @@ class ShardedCodebookSearch:
         if self.world == 1:
             return keys
         if self.reduction == "all_gather":
-            every = torch.empty((self.world, keys.shape[0]), dtype=torch.int64, device=keys.device)
+            every = torch.empty((self.world * keys.shape[0],), dtype=torch.int64, device=keys.device)
             dist.all_gather_into_tensor(every, keys.contiguous(), group=self.group)
-            return every.amin(dim=0)
+            return every.view(self.world, keys.shape[0]).amin(dim=0)
         dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.group)
         return keys
 
