@@ -16,7 +16,7 @@ import json
 import os
 import sys
 
-KERNEL = "vq_search_mfma"
+KERNEL = "vq_search_"  # vq_search_mfma<...> or, for 256 < D <= 512, vq_search_pair512<...>
 
 
 def find(raw, wl, sub, pattern):
@@ -71,7 +71,7 @@ def main():
                 "hbm_bytes_per_launch": int(round(hbm)), "FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"],
                 "kernel": kernel_names,
                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --workload %s --no-legs "
-                        "--no-cpu-baseline --no-sharded --steps 20 --warmup 5`, mean over the vq_search_mfma dispatches; gfx950 "
+                        "--no-cpu-baseline --no-sharded --steps 20 --warmup 5`, mean over the search kernel's dispatches; gfx950 "
                         "correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request -> doubled; WRITE_SIZE "
                         "exact. hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024" % wl}
         pmc["kernel"] = kernel_names

@@ -22,6 +22,7 @@
 //   vq_common.inc        constants, error strings, padded-dim table, packed (value, index) keys
 //   vq_pack.inc          natural codebook -> packed image
 //   vq_search.inc        the hot kernel (tile geometry, LDS-DMA staging, MFMA fragment pipeline, tie-exact epilogue, finalize)
+//   vq_search_pair.inc   the same search for 256 < D <= 512 with the dims split over a pair of waves (accumulator hand-off)
 //   vq_similarity.inc    the same sweep with the similarity / online-softmax epilogues, fused cross-entropy backward
 //   vq_finalize_ema.inc  scalar fallback search, finalize-from-keys, loss reduction, EMA codebook update
 //   this file            host-side dispatch and the C ABI (include/vq_mi355x.h)
@@ -46,6 +47,7 @@ namespace {
 #include "vq_common.inc"
 #include "vq_pack.inc"
 #include "vq_search.inc"
+#include "vq_search_pair.inc"
 #include "vq_similarity.inc"
 #include "vq_finalize_ema.inc"
 
@@ -152,7 +154,36 @@ int launch_search_m(const SearchParams &p, int H, int splits, int metric, hipStr
     return launch_search_t<DP, WAVES, VQ_METRIC_DOT, 0>(p, H, splits, s);
 }
 
+// 256 < D <= 512: dims split over wave pairs (vq_search_pair.inc); 8 waves = 4 pairs = 128 rows per workgroup
+template <int METRIC, bool LSE = false, int XT = 0>
+int launch_pair_t(const SearchParams &p, int H, int splits, hipStream_t s) {
+    const size_t lds = PairGeo::lds_bytes(1, false);
+    auto kern = vq_search_pair512<METRIC, LSE, XT>;
+    static thread_local bool attr_done[kMaxDevices] = {};
+    if (int rc = allow_big_lds(kern, attr_done)) return rc;
+    dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)H, (unsigned)splits);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_search_pair512 launch");
+    return 0;
+}
+
+int launch_pair(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    const bool eu = metric == VQ_METRIC_EUCLID;
+    if (p.xt == 1) return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 1>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 1>(p, H, splits, s);
+    if (p.xt == 2) return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 2>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 2>(p, H, splits, s);
+    if (p.lse) return eu ? launch_pair_t<VQ_METRIC_EUCLID, true>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, true>(p, H, splits, s);
+    return eu ? launch_pair_t<VQ_METRIC_EUCLID>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT>(p, H, splits, s);
+}
+
+// VQ_SINGLE_WAVE_512=1 in the environment selects the one-wave-per-row-block kernel for D > 256 (A/B measurements)
+bool use_pair512() {
+    static const bool off = getenv("VQ_SINGLE_WAVE_512") != nullptr;
+    return !off;
+}
+
 int launch_search(int DP, int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    if (DP == 512 && p.Q == 1 && use_pair512()) return launch_pair(p, H, splits, metric, s);  // single stage: wave pairs
     switch (DP) {
         case 32: return waves == 8 ? launch_search_m<32, 8>(p, H, splits, metric, s) : launch_search_m<32, 4>(p, H, splits, metric, s);
         case 64: return waves == 8 ? launch_search_m<64, 8>(p, H, splits, metric, s) : launch_search_m<64, 4>(p, H, splits, metric, s);
@@ -234,7 +265,8 @@ int check_common(const vq_args *a) {
 
 // Workspace layout: [keys: H*M int64][loss partials: floats]
 long long ws_keys_bytes(int H, long long M) { return ((long long)H * M * 8 + 255) / 256 * 256; }
-long long ws_loss_floats(int H, long long M, int Q) { return (long long)H * ((M + 31) / 32 + 8) * Q + (long long)H * 8192 + 64; }
+// loss partials: one float per wave, stage and 32 rows (16 rows for the wave-pair kernel of 256 < D <= 512)
+long long ws_loss_floats(int H, long long M, int Q) { return (long long)H * ((M + 15) / 16 + 16) * Q + (long long)H * 8192 + 64; }
 
 void fill_search_params(SearchParams &p, const vq_args *a) {
     memset(&p, 0, sizeof(p));
@@ -482,8 +514,9 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         rc = launch_search(DP, waves, p, a->H, 1, a->metric, s);
         if (rc) return rc;
         if (a->sq_err) {
-            const long long rows_per_wg = 32ll * waves;
-            const long long per_head = ((a->M + rows_per_wg - 1) / rows_per_wg) * waves;
+            const bool pair = DP == 512 && a->Q == 1 && use_pair512();  // 8 waves (4 pairs) per 128 rows, one partial per wave
+            const long long rows_per_wg = pair ? 128 : 32ll * waves;
+            const long long per_head = ((a->M + rows_per_wg - 1) / rows_per_wg) * (pair ? 8 : waves);
             const bool by_head = (a->flags & VQ_F_SQERR_PER_HEAD) != 0;
             hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(a->Q, by_head ? a->H : 1), dim3(256), 0, s, loss_part,
                                by_head ? per_head : per_head * a->H, a->Q, a->sq_err);
