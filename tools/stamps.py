@@ -35,7 +35,7 @@ buf = (ctypes.c_uint64 * (8192 * NST))()
 lib.vq_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 rc = lib.vq_debug_read_stamps(buf, 8192 * NST)
 st = np.frombuffer(buf, dtype=np.uint64).reshape(8192, NST).astype(np.int64)
-nw = min(8192, (M + 31) // 32)
+nw = min(8192, (M + 15) // 16 if (D > 256 and Q == 1) else (M + 31) // 32)  # wave pairs: 8 waves per 128 rows
 st = st[:nw]
 pro = st[:, 1] - st[:, 0]; sweep = st[:, 2] - st[:, 1]; fin = st[:, 3] - st[:, 2]
 print("rc", rc, "waves", nw)

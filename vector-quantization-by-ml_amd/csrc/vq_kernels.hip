@@ -182,8 +182,11 @@ bool use_pair512() {
     return !off;
 }
 
+// The wave-pair kernel runs wave B one tile behind wave A: one extra step per sweep.  Worth it from 8 tiles per sweep on.
+bool pair_selected(int DP, int Q, int tiles_per_sweep) { return DP == 512 && Q == 1 && tiles_per_sweep >= 8 && use_pair512(); }
+
 int launch_search(int DP, int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
-    if (DP == 512 && p.Q == 1 && use_pair512()) return launch_pair(p, H, splits, metric, s);  // single stage: wave pairs
+    if (pair_selected(DP, p.Q, p.tiles_per_split)) return launch_pair(p, H, splits, metric, s);  // single stage: wave pairs
     switch (DP) {
         case 32: return waves == 8 ? launch_search_m<32, 8>(p, H, splits, metric, s) : launch_search_m<32, 4>(p, H, splits, metric, s);
         case 64: return waves == 8 ? launch_search_m<64, 8>(p, H, splits, metric, s) : launch_search_m<64, 4>(p, H, splits, metric, s);
@@ -514,7 +517,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         rc = launch_search(DP, waves, p, a->H, 1, a->metric, s);
         if (rc) return rc;
         if (a->sq_err) {
-            const bool pair = DP == 512 && a->Q == 1 && use_pair512();  // 8 waves (4 pairs) per 128 rows, one partial per wave
+            const bool pair = pair_selected(DP, a->Q, p.tiles_per_split);  // 8 waves (4 pairs) per 128 rows, one partial per wave
             const long long rows_per_wg = pair ? 128 : 32ll * waves;
             const long long per_head = ((a->M + rows_per_wg - 1) / rows_per_wg) * (pair ? 8 : waves);
             const bool by_head = (a->flags & VQ_F_SQERR_PER_HEAD) != 0;
