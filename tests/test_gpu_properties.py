@@ -420,3 +420,27 @@ def test_c_abi_rejects_bad_arguments_without_launching():
         native.quantize(x, cb, flags=native.F_FORCE_SIMPLE, want_lse=True)
     with pytest.raises(native.NativeUnavailable):
         native.quantize(x.cpu(), cb.cpu())
+
+
+def test_non_finite_rows_do_not_disturb_their_neighbours():
+    """Non-finite inputs are outside the arithmetic contract (ATen's argmax returns the first NaN position, the
+    in-lane min tree ignores NaN), but they must stay LOCAL: a row of NaN / inf yields some in-range index, and every other
+    row of the same wave, workgroup and launch is unaffected -- for the one-wave and the wave-pair kernels."""
+    native = _native()
+    for (M, K, D) in ((40000, 300, 64), (40000, 1000, 256), (40000, 200, 384)):
+        g = torch.Generator().manual_seed(D)
+        x = torch.randn((1, M, D), generator=g).to(DEV)
+        cb = torch.randn((1, 1, K, D), generator=g).to(DEV)
+        clean = native.quantize(x, cb)
+        bad = x.clone()
+        bad[0, 5, 3] = float("nan")
+        bad[0, 77, :] = float("inf")
+        bad[0, 1000, 0] = float("-inf")
+        r = native.quantize(bad, cb)
+        torch.cuda.synchronize()
+        idx = r["idx"][0, :, 0]
+        assert int(idx.min()) >= 0 and int(idx.max()) < K
+        keep = torch.ones(M, dtype=torch.bool, device=DEV)
+        keep[[5, 77, 1000]] = False
+        assert torch.equal(idx[keep], clean["idx"][0, :, 0][keep])
+        assert torch.equal(r["out"][0][keep], clean["out"][0][keep])
