@@ -96,7 +96,15 @@ def main():
             except Exception:
                 pass
         json.dump(pmc, open(os.path.join(out, f"r02_{wl}_pmc.json"), "w"), indent=1)
-    json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    tpath = os.path.join(out, "traffic.json")
+    merged = {}
+    if os.path.exists(tpath):  # a partial re-run (some workloads only) keeps the others' entries
+        try:
+            merged = json.load(open(tpath))
+        except Exception:
+            merged = {}
+    merged.update(traffic)
+    json.dump(merged, open(tpath, "w"), indent=1)
     print(json.dumps(traffic, indent=1))
 
 
