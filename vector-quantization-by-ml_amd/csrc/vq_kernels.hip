@@ -350,9 +350,12 @@ int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hip
         waves = 4;
         wgs = (long long)a->H * ((a->M + 127) / 128);
     }
+    // K is split until the chip is full: two 4-wave workgroups fit a CU at Dp <= 256, one (LDS) at Dp = 512 -- splitting
+    // further only repeats the prologue and, in the wave-pair kernel, the extra pipeline step
+    const long long fill = (long long)cus * (DP == 512 ? 1 : 2);
     int splits = 1;
-    if (wgs < 2 * cus) {
-        splits = (int)((2 * cus + wgs - 1) / wgs);
+    if (wgs < fill) {
+        splits = (int)((fill + wgs - 1) / wgs);
         if (splits > p.ntiles) splits = p.ntiles;
         if (splits < 1) splits = 1;
     }
