@@ -303,7 +303,9 @@ def run_workload(name, args, device, rank, world, want_parity):
     ab = algorithmic_bytes_per_step(w)
     roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic_record(name),
-                kernel="vq_search_pair512" if (head_dim(w) > 256 and w.get("Q", 1) == 1) else "vq_search_mfma",
+                kernel=("vq_search_pair512" if (head_dim(w) > 256 and w.get("Q", 1) == 1) else
+                        "vq_search_persist" if (128 < head_dim(w) <= 256 and w.get("Q", 1) == 1 and 1024 <= w["K"] <= 3072) else
+                        "vq_search_mfma"),
                 kernel_ms=round(live_ms, 4), kernel_ms_isolated=round(iso_ms, 4), launches_timed=len(kernel_events),
                 algorithmic_flops_per_launch=fl, algorithmic_hbm_bytes_per_launch=ab,
                 hbm_gbs_algorithmic=round(ab / (live_ms * 1e-3) / 1e9, 1), hbm_frac_of_peak=round(ab / (live_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))

@@ -23,6 +23,7 @@
 //   vq_pack.inc          natural codebook -> packed image
 //   vq_search.inc        the hot kernel (tile geometry, LDS-DMA staging, MFMA fragment pipeline, tie-exact epilogue, finalize)
 //   vq_search_pair.inc   the same search for 256 < D <= 512 with the dims split over a pair of waves (accumulator hand-off)
+//   vq_search_persist.inc  inference search at Dp = 256 with block b's gather hidden inside block b + 1's sweep
 //   vq_similarity.inc    the same sweep with the similarity / online-softmax epilogues, fused cross-entropy backward
 //   vq_finalize_ema.inc  scalar fallback search, finalize-from-keys, loss reduction, EMA codebook update
 //   this file            host-side dispatch and the C ABI (include/vq_mi355x.h)
@@ -48,6 +49,7 @@ namespace {
 #include "vq_pack.inc"
 #include "vq_search.inc"
 #include "vq_search_pair.inc"
+#include "vq_search_persist.inc"
 #include "vq_similarity.inc"
 #include "vq_finalize_ema.inc"
 
@@ -185,7 +187,43 @@ bool use_pair512() {
 // The wave-pair kernel runs wave B one tile behind wave A: one extra step per sweep.  Worth it from 8 tiles per sweep on.
 bool pair_selected(int DP, int Q, int tiles_per_sweep) { return DP == 512 && Q == 1 && tiles_per_sweep >= 8 && use_pair512(); }
 
+// Plain inference call at Dp = 256 (one stage, no straight-through, no loss, aligned fp32 rows, >= 32 sub-tiles per sweep,
+// several row blocks per CU): persistent workgroups that copy block b's winners during block b + 1's sweep.
+// VQ_NO_PERSIST=1 in the environment keeps the one-block-per-workgroup kernel (A/B measurements).
+bool persist_selected(int DP, int waves, const SearchParams &p, int H, int splits, int cus) {
+    static const bool off = getenv("VQ_NO_PERSIST") != nullptr;
+    if (off || DP != 256 || waves != 8 || splits != 1 || p.Q != 1 || p.mode != kModeFused) return false;
+    if (p.ste || p.loss_part || p.lse || p.xt || !p.vec_x || !p.vec_fin || !p.out || p.D % 4) return false;
+    const int nsub = p.ntiles * sub_tiles(DP);
+    if (nsub < 32 || nsub > 96) return false;  // one row per sub-tile needs 32; beyond ~100 the finalize is < 1 % of a block
+    const long long nblk = (p.M + 32 * waves - 1) / (32 * waves);
+    return nblk * H >= 2ll * cus;  // at least two blocks per resident workgroup
+}
+
+template <int METRIC>
+int launch_persist_t(const SearchParams &p, int H, int cus, hipStream_t s) {
+    using G = Geo<256, 8>;
+    const size_t lds = (size_t)G::MAIN_FLOATS * 4 + 2 * 8 * 32 * 4;
+    auto kern = vq_search_persist<256, 8, METRIC>;
+    static thread_local bool attr_done[kMaxDevices] = {};
+    if (int rc = allow_big_lds(kern, attr_done)) return rc;
+    const long long nblk = (p.M + 255) / 256;
+    long long gx = cus / H;  // one 8-wave workgroup per CU (219 VGPRs): resident workgroups = CUs, shared by the heads
+    if (gx < 1) gx = 1;
+    if (gx > nblk) gx = nblk;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)H, 1), dim3(512), lds, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_search_persist launch");
+    return 0;
+}
+
 int launch_search(int DP, int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    {
+        const DevInfo &di = dev_info();
+        const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+        if (persist_selected(DP, waves, p, H, splits, cus))
+            return metric == VQ_METRIC_EUCLID ? launch_persist_t<VQ_METRIC_EUCLID>(p, H, cus, s) : launch_persist_t<VQ_METRIC_DOT>(p, H, cus, s);
+    }
     if (pair_selected(DP, p.Q, p.tiles_per_split)) return launch_pair(p, H, splits, metric, s);  // single stage: wave pairs
     switch (DP) {
         case 32: return waves == 8 ? launch_search_m<32, 8>(p, H, splits, metric, s) : launch_search_m<32, 4>(p, H, splits, metric, s);
