@@ -1,0 +1,73 @@
+"""Randomised cross-check of the MFMA kernels (dev tool, GPU box):  python tools/fuzz_kernels.py [seconds] [seed]
+
+Single stage: random (H, M, K, D, metric, ste) -> the launcher's choice (one-block, persistent, wave-pair, split-K) must equal
+the scalar kernel bit for bit (indices, winning values, outputs) -- both follow the oracle's k-ordered chain.
+Residual stacks: random (Q, M, K, D, train) against the CPU oracle (indices and outputs exact)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vector-quantization-by-ml_amd")]
+import numpy as np
+import torch
+from oracle import vq_oracle
+from vector_quantization import native
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda:0")
+native.load()
+t_end = time.time() + budget
+n1 = n2 = 0
+while time.time() < t_end:
+    if rng.random() < 0.7:
+        D = int(rng.choice([5, 24, 32, 48, 64, 100, 128, 132, 200, 256, 260, 300, 384, 500, 512]))
+        K = int(rng.choice([1, 7, 33, 100, 256, 1000, 1024, 1100, 2048, 3000, 4100]))
+        H = int(rng.choice([1, 1, 2, 3]))
+        big = rng.random() < 0.5
+        M = int(rng.integers(140000, 300000) // H) if big else int(rng.integers(1, 40000))
+        if D > 256 and big:
+            M = int(rng.integers(33000, 70000) // H)
+        metric = int(rng.integers(0, 2))
+        ste = bool(rng.integers(0, 2))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        grid = rng.random() < 0.25  # exact-grid values: forced ties
+        if grid:
+            x = (torch.randint(-8, 9, (H, M, D), generator=g).float() / 4.0).to(dev)
+            cb = (torch.randint(-8, 9, (H, 1, K, D), generator=g).float() / 4.0).to(dev)
+        else:
+            x = torch.randn((H, M, D), generator=g).to(dev)
+            cb = torch.randn((H, 1, K, D), generator=g).to(dev)
+        a = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=ste)
+        s = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=ste, flags=native.F_FORCE_SIMPLE)
+        torch.cuda.synchronize()
+        ok = (torch.equal(a["idx"], s["idx"]) and torch.equal(a["best"].view(torch.int32), s["best"].view(torch.int32))
+              and torch.equal(a["out"], s["out"]))
+        if not ok:
+            bad = int((a["idx"] != s["idx"]).sum())
+            print(f"MISMATCH single: H={H} M={M} K={K} D={D} metric={metric} ste={ste} grid={grid}: {bad} indices differ", flush=True)
+            sys.exit(1)
+        n1 += 1
+    else:
+        D = int(rng.choice([24, 40, 64, 100, 128, 200, 256, 300, 512]))
+        K = int(rng.choice([7, 64, 100, 256, 1000]))
+        Q = int(rng.integers(2, 7))
+        M = int(rng.integers(1, 3000))
+        train = bool(rng.integers(0, 2))
+        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randn((M, D), generator=g)
+        cbs = torch.stack([torch.randn((K, D), generator=g) * 2.0 ** (-i / 2.0) for i in range(Q)])
+        ref = vq_oracle.rvq_forward(x.numpy(), cbs.numpy(), 0, training=train)
+        r = native.quantize(x[None].to(dev), cbs[None].contiguous().to(dev), ste=train, want_sq_err=train)
+        torch.cuda.synchronize()
+        ok = (np.array_equal(r["idx"][0].cpu().numpy(), ref["idx"]) and np.array_equal(r["out"][0].cpu().numpy(), ref["out"])
+              and np.array_equal(r["best"][0].cpu().numpy().view(np.uint32), ref["best"].view(np.uint32)))
+        if not ok:
+            print(f"MISMATCH residual: Q={Q} M={M} K={K} D={D} train={train}", flush=True)
+            sys.exit(1)
+        n2 += 1
+    if (n1 + n2) % 20 == 0:
+        print(f"{n1} single-stage, {n2} residual configurations agree", flush=True)
+print(f"done: {n1} single-stage and {n2} residual random configurations, all bit-exact", flush=True)
