@@ -100,13 +100,13 @@ int allow_big_lds(K kern, bool (&done)[kMaxDevices]) {
     return 0;
 }
 
-template <int DP, int WAVES, int METRIC, int MULTI, bool LSE = false, int XT = 0>
+template <int DP, int WAVES, int METRIC, int MULTI, bool LSE = false, int XT = 0, int WIDE = 0>
 int launch_search_t(const SearchParams &p, int H, int splits, hipStream_t s) {
     using G = Geo<DP, WAVES>;
     const size_t lds = (size_t)(MULTI ? G::MAIN_FLOATS_M : G::MAIN_FLOATS) * 4 + (size_t)WAVES * p.Q * 32 * 4 +
                        ((MULTI && p.loss_part) ? (size_t)WAVES * p.Q * 64 * 4 : 0);
     if (lds > 160 * 1024) return fail(VQ_E_UNSUPPORTED, "vq_search: LDS budget exceeded (too many residual stages)");
-    auto kern = vq_search_mfma<DP, WAVES, METRIC, MULTI, LSE, XT>;
+    auto kern = vq_search_mfma<DP, WAVES, METRIC, MULTI, LSE, XT, WIDE>;
     static thread_local bool attr_done[kMaxDevices] = {};
     if (int rc = allow_big_lds(kern, attr_done)) return rc;
     const long long rows_per_wg = 32ll * WAVES;
@@ -323,6 +323,7 @@ void fill_search_params(SearchParams &p, const vq_args *a) {
         p.ntiles = (a->K + tc - 1) / tc;
     }
     p.tiles_per_split = p.ntiles;
+    p.key_hs = a->M;
     p.pk_bytes = (unsigned)(vq_packed_floats(a->K, a->D) * 4);
     p.ste = (a->flags & VQ_F_STE) ? 1 : 0;
     p.xt = (a->flags & VQ_F_X_F16) ? 1 : ((a->flags & VQ_F_X_BF16) ? 2 : 0);
@@ -353,8 +354,130 @@ int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipS
     return 0;
 }
 
+// ---- rows wider than 512 dims -------------------------------------------------------------------
+// The distance of a (row, code) pair is ONE k-ordered fmaf chain over all dims, so the sweep is cut along d into slices of
+// 512 dims: slice j continues the chains slice j - 1 left in the workspace (the accumulators' own fragment layout: every
+// lane reads back exactly the 16-byte pieces it wrote, coalesced), and the last slice closes them with the norms and runs
+// the argmin into packed keys.  The workspace holds the chains of one (row chunk) x (code chunk) at a time.
+constexpr int kWideSlice = 512;
+constexpr long long kWideChunkBytes = 512ll << 20;  // accumulator workspace per (row chunk, code chunk)
+constexpr int kWideCodes = 4096;                    // codes per chunk
+
+struct WidePlan {
+    int nd;            // 512-dim slices
+    int kc;            // codes per chunk (multiple of 32)
+    long long mc;      // rows per chunk (multiple of 128)
+    long long acc_bytes, xn_bytes;
+};
+
+WidePlan wide_plan(int H, long long M, int K, int D) {
+    WidePlan w;
+    w.nd = (D + kWideSlice - 1) / kWideSlice;
+    const int Kp = round_up(K, kTileCodes);
+    w.kc = Kp < kWideCodes ? Kp : kWideCodes;
+    const long long Mp = (M + 127) / 128 * 128;
+    long long mc = kWideChunkBytes / ((long long)H * w.kc * 4) / 128 * 128;
+    if (mc < 128) mc = 128;
+    if (mc > Mp) mc = Mp;
+    w.mc = mc;
+    w.acc_bytes = (long long)H * mc * w.kc * 4;
+    w.xn_bytes = ((long long)H * mc * 4 + 255) / 256 * 256;
+    return w;
+}
+
+long long wide_image_floats(int K) { return (long long)round_up(K, kTileCodes) * (kWideSlice + 4) + kPackSlack; }
+// the last slice is padded like a narrow row of its own width (32 ... 512 dims) and packed in that layout
+int wide_last_dims(int D) { return D - (D - 1) / kWideSlice * kWideSlice; }
+long long wide_last_image_floats(int K, int D) {
+    const int DP = padded_dim(wide_last_dims(D));
+    return (long long)round_up(K, kTileCodes * sub_tiles(DP)) * (DP + 4) + kPackSlack;
+}
+
+template <int DP, int WIDE>
+int launch_wide_t(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, 4, VQ_METRIC_EUCLID, 0, false, 0, WIDE>(p, H, splits, s);
+    return launch_search_t<DP, 4, VQ_METRIC_DOT, 0, false, 0, WIDE>(p, H, splits, s);
+}
+
+int launch_wide_last(int DP, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    switch (DP) {
+        case 32: return launch_wide_t<32, 2>(p, H, splits, metric, s);
+        case 64: return launch_wide_t<64, 2>(p, H, splits, metric, s);
+        case 128: return launch_wide_t<128, 2>(p, H, splits, metric, s);
+        case 256: return launch_wide_t<256, 2>(p, H, splits, metric, s);
+        case 512: return launch_wide_t<512, 2>(p, H, splits, metric, s);
+    }
+    return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
+}
+
+int run_search_keys_wide(const vq_args *a, long long idx_offset, long long *keys, hipStream_t s) {
+    if (!a->packed) return fail(VQ_E_BADARG, "vq: packed codebook is null");
+    if (a->flags & (VQ_F_X_F16 | VQ_F_X_BF16)) return fail(VQ_E_UNSUPPORTED, "vq: 2-byte rows need D <= 512");
+    const long long img = wide_image_floats(a->K);
+    if (img * 4 >= (1ll << 31)) return fail(VQ_E_UNSUPPORTED, "vq: packed codebook image >= 2 GiB (shard the codebook)");
+    const WidePlan w = wide_plan(a->H, a->M, a->K, a->D);
+    const long long base = vq_workspace_bytes(a->H, a->M, 1);
+    if (!a->workspace || a->workspace_bytes < base + w.acc_bytes + w.xn_bytes)
+        return fail(VQ_E_BADARG, "vq: workspace too small for rows wider than 512 dims (see vq_workspace_bytes_wide)");
+    float *acc_ws = (float *)((char *)a->workspace + base);
+    float *xn_ws = (float *)((char *)a->workspace + base + w.acc_bytes);
+    const DevInfo &di = dev_info();
+    const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+    const int Kp = round_up(a->K, kTileCodes);
+    const int d_last = wide_last_dims(a->D), dp_last = padded_dim(d_last);
+    for (long long m0 = 0; m0 < a->M; m0 += w.mc) {
+        const long long mrows = (a->M - m0 < w.mc) ? a->M - m0 : w.mc;
+        const long long nblk = (mrows + 127) / 128;
+        for (int k0 = 0; k0 < Kp; k0 += w.kc) {
+            const int kcodes = (a->K - k0 < w.kc) ? a->K - k0 : w.kc;  // real codes of this chunk (> 0: k0 < Kp, K > Kp - 32)
+            const int nsub = (kcodes + kTileCodes - 1) / kTileCodes;
+            for (int j = 0; j < w.nd; ++j) {
+                const bool last = j + 1 == w.nd;
+                const int DP = last ? dp_last : kWideSlice;
+                const int rs = DP + 4;                                        // packed row stride of this slice's image
+                const long long img_j = last ? wide_last_image_floats(a->K, a->D) : img;
+                SearchParams p;
+                memset(&p, 0, sizeof(p));
+                p.x = a->x + m0 * a->x_rs + (long long)j * kWideSlice;
+                p.x_rs = a->x_rs; p.x_hs = a->x_hs;
+                p.packed = a->packed + (long long)j * img + (long long)k0 * rs;
+                p.pk_hs = a->pk_hs;
+                p.pk_bytes = (unsigned)((img_j - (long long)k0 * rs) * 4);
+                p.M = mrows; p.K = kcodes; p.D = last ? d_last : kWideSlice; p.Q = 1;
+                const int tc = kTileCodes * sub_tiles(DP);
+                p.ntiles = (kcodes + tc - 1) / tc;
+                // K is split over workgroups until the chip is full (one 4-wave workgroup per CU at Dp = 512, two below)
+                const long long fill = (long long)cus * (DP == 512 ? 1 : 2);
+                int splits = 1;
+                if (nblk * a->H < fill) {
+                    splits = (int)((fill + nblk * a->H - 1) / (nblk * a->H));
+                    if (splits > p.ntiles) splits = p.ntiles;
+                }
+                p.tiles_per_split = (p.ntiles + splits - 1) / splits;
+                splits = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+                p.mode = kModeKeys;
+                p.keys = keys + m0;
+                p.key_hs = a->M;
+                p.idx_offset = idx_offset + k0;
+                p.vec_x = (p.D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x)) ? 1 : 0;
+                p.acc_ws = acc_ws;
+                p.ws_hs = nblk * 4 * (long long)nsub * 256;
+                p.ws_nsub = nsub;
+                p.acc_in = j > 0;
+                p.xn_ws = xn_ws;
+                p.xn_hs = w.mc;
+                const int rc = last ? launch_wide_last(DP, p, a->H, splits, a->metric, s)
+                                    : launch_wide_t<kWideSlice, 1>(p, a->H, splits, a->metric, s);
+                if (rc) return rc;
+            }
+        }
+    }
+    return 0;
+}
+
 int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hipStream_t s) {
     const int DP = padded_dim(a->D);
+    if (DP == 0 && !(a->flags & VQ_F_FORCE_SIMPLE)) return run_search_keys_wide(a, idx_offset, keys, s);
     const bool simple = (a->flags & VQ_F_FORCE_SIMPLE) || DP == 0;
     if (simple) {
         if (!a->cb) return fail(VQ_E_BADARG, "vq: natural codebook required for the scalar kernel");
@@ -427,8 +550,17 @@ int vq_device_info(char *buf, size_t n) {
 int64_t vq_packed_floats(int K, int D) {
     if (K <= 0 || D <= 0) return 0;
     const int DP = padded_dim(D);
-    if (DP == 0) return 4;  // scalar kernel reads the natural codebook
+    if (DP == 0)  // one image per 512-dim slice, the last one in the layout of its own (padded) width
+        return (int64_t)((D - 1) / kWideSlice) * wide_image_floats(K) + wide_last_image_floats(K, D);
     return (int64_t)round_up(K, kTileCodes * sub_tiles(DP)) * (DP + 4) + kPackSlack;
+}
+
+int64_t vq_workspace_bytes_wide(int H, int64_t M, int K, int D) {
+    if (H <= 0 || M < 0 || K <= 0 || D <= 0) return 0;
+    const int64_t base = vq_workspace_bytes(H, M, 1);
+    if (padded_dim(D) != 0 || M == 0) return base;
+    const WidePlan w = wide_plan(H, M, K, D);
+    return base + w.acc_bytes + w.xn_bytes;
 }
 
 int64_t vq_workspace_bytes(int H, int64_t M, int Q) {
@@ -441,14 +573,25 @@ int vq_pack_codebooks_f32(const float *cb, int n_codebooks, int64_t cb_stride, i
     if (!cb || !packed || n_codebooks <= 0 || K <= 0 || D <= 0) return fail(VQ_E_BADARG, "vq_pack: bad argument");
     if (metric != VQ_METRIC_EUCLID && metric != VQ_METRIC_DOT) return fail(VQ_E_BADARG, "vq_pack: unknown metric");
     const int DP = padded_dim(D);
-    if (DP == 0) return 0;  // nothing to pack: the scalar kernel is used for D > 512
     if (!aligned16(packed)) return fail(VQ_E_BADARG, "vq_pack: packed buffer must be 16-byte aligned");
-    const int Kp = round_up(K, kTileCodes * sub_tiles(DP));
     const long long pk_stride = vq_packed_floats(K, D);
     hipStream_t s = (hipStream_t)stream;
+    if (DP == 0) {  // rows wider than 512 dims: one image per 512-dim slice
+        const int nd = (D + kWideSlice - 1) / kWideSlice;
+        for (int j = 0; j < nd; ++j) {
+            const int dp = (j + 1 == nd) ? padded_dim(wide_last_dims(D)) : kWideSlice;
+            const int Kp = round_up(K, kTileCodes * sub_tiles(dp));
+            hipLaunchKernelGGL(vq_pack_kernel, dim3(Kp / 64 + 1, n_codebooks), dim3(64), 0, s, cb, (long long)cb_stride, K, Kp,
+                               D, j * kWideSlice, dp, metric, packed + (long long)j * wide_image_floats(K), pk_stride);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "vq_pack launch");
+        return 0;
+    }
+    const int Kp = round_up(K, kTileCodes * sub_tiles(DP));
     // grid covers Kp rows plus at least one extra block whose threads zero the over-copy slack
     hipLaunchKernelGGL(vq_pack_kernel, dim3(Kp / 64 + 1, n_codebooks), dim3(64), 0, s, cb, (long long)cb_stride, K, Kp,
-                       D, DP, metric, packed, pk_stride);
+                       D, 0, DP, metric, packed, pk_stride);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "vq_pack launch");
     return 0;

@@ -97,6 +97,8 @@ def load():
         lib.vq_packed_floats.restype = _i64
         lib.vq_workspace_bytes.argtypes = [ctypes.c_int, _i64, ctypes.c_int]
         lib.vq_workspace_bytes.restype = _i64
+        lib.vq_workspace_bytes_wide.argtypes = [ctypes.c_int, _i64, ctypes.c_int, ctypes.c_int]
+        lib.vq_workspace_bytes_wide.restype = _i64
         lib.vq_pack_codebooks_f32.argtypes = [_vp, ctypes.c_int, _i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp]
         lib.vq_pack_codebooks_f32.restype = ctypes.c_int
         lib.vq_quantize_lse_f32.argtypes = [ap, _vp, _vp]
@@ -136,7 +138,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = (
-    "vq_packed_floats", "vq_pack_codebooks_f32", "vq_workspace_bytes", "vq_quantize_f32", "vq_nearest_f32",
+    "vq_packed_floats", "vq_pack_codebooks_f32", "vq_workspace_bytes", "vq_workspace_bytes_wide", "vq_quantize_f32", "vq_nearest_f32",
     "vq_residual_f32", "vq_keys_init", "vq_search_keys_f32", "vq_finalize_keys_f32", "vq_last_error",
     "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32", "vq_similarities_f32", "vq_softmax_stats_f32",
     "vq_ce_backward_f32", "vq_quantize_lse_f32",
@@ -194,8 +196,10 @@ def pack_codebooks(cb: torch.Tensor, metric: int) -> torch.Tensor:
     return packed
 
 
-def _workspace(H: int, M: int, Q: int, device) -> torch.Tensor:
+def _workspace(H: int, M: int, Q: int, device, K: int = 0, D: int = 0) -> torch.Tensor:
     nbytes = int(load().vq_workspace_bytes(H, M, Q))
+    if D > 512:  # rows wider than 512 dims: room for the distance chains carried between the 512-dim slices
+        nbytes = max(nbytes, int(load().vq_workspace_bytes_wide(H, M, K, D)))
     return torch.empty((nbytes + 15) // 16 * 2, dtype=torch.float64, device=device)
 
 
@@ -258,7 +262,7 @@ def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bo
     else:
         out, o_rs, o_hs = None, 0, 0
     sq_err = torch.empty((H, Q) if sq_err_per_head else (Q,), dtype=torch.float64, device=dev) if want_sq_err else None
-    ws = _workspace(H, M, Q, dev)
+    ws = _workspace(H, M, Q, dev, K, D)
     a = VqArgs()
     a.H, a.Q, a.M, a.K, a.D, a.metric = H, Q, M, K, D, metric
     a.flags = flags | (F_STE if ste else 0) | (F_SQERR_PER_HEAD if (sq_err_per_head and want_sq_err) else 0)
@@ -310,6 +314,9 @@ def search_keys(x: torch.Tensor, cb: torch.Tensor, keys: torch.Tensor, *, metric
     a.x, a.x_rs, a.x_hs = x.data_ptr(), x_rs, x_hs
     a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), K * D, 0
     a.packed, a.pk_hs, a.pk_qs = packed.data_ptr(), packed.shape[-1], 0
+    if D > 512:
+        ws = _workspace(H, M, 1, x.device, K, D)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8
     with torch.cuda.device(x.device):
         _check(load().vq_search_keys_f32(ctypes.byref(a), idx_offset, keys.data_ptr(), _stream_ptr(x.device)),
                "vq_search_keys_f32")
