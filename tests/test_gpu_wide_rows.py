@@ -79,6 +79,8 @@ def test_wide_rows_training_outputs(oracle, H, M, K, D, metric):
     (8, 4200, 4100, 520, 0),    # heads shrink the row chunk to 4096 rows: two row chunks x two code chunks
     (1, 70000, 300, 1030, 0),   # one chunk, 547 row blocks, three slices
     (2, 9000, 5000, 777, 1),
+    (1, 1460, 5000, 2056, 0),   # five slices, K split 22 ways, two code chunks: the |x|^2 chain is read and written by every split
+    (1, 20000, 1000, 1600, 0),
 ])
 def test_wide_rows_chunked_equals_scalar_kernel(oracle, H, M, K, D, metric):
     native = _native()

@@ -2,6 +2,7 @@
 
 Single stage: random (H, M, K, D, metric, ste) -> the launcher's choice (one-block, persistent, wave-pair, split-K) must equal
 the scalar kernel bit for bit (indices, winning values, outputs) -- both follow the oracle's k-ordered chain.
+Rows wider than 512 dims (sliced sweep, chains carried through the workspace): the same check, D up to 2100.
 Residual stacks: random (Q, M, K, D, train) against the CPU oracle (indices and outputs exact)."""
 import os
 import sys
@@ -20,16 +21,24 @@ rng = np.random.default_rng(seed)
 dev = torch.device("cuda:0")
 native.load()
 t_end = time.time() + budget
-n1 = n2 = 0
+n1 = n2 = n3 = 0
 while time.time() < t_end:
-    if rng.random() < 0.7:
-        D = int(rng.choice([5, 24, 32, 48, 64, 100, 128, 132, 200, 256, 260, 300, 384, 500, 512]))
-        K = int(rng.choice([1, 7, 33, 100, 256, 1000, 1024, 1100, 2048, 3000, 4100]))
-        H = int(rng.choice([1, 1, 2, 3]))
-        big = rng.random() < 0.5
-        M = int(rng.integers(140000, 300000) // H) if big else int(rng.integers(1, 40000))
-        if D > 256 and big:
-            M = int(rng.integers(33000, 70000) // H)
+    pick = rng.random()
+    if pick < 0.7:
+        wide = pick < 0.2
+        if wide:
+            D = int(rng.integers(513, 2100))
+            K = int(rng.choice([1, 7, 33, 100, 256, 1000, 1024, 1100, 4100, 5000, 8200]))
+            H = int(rng.choice([1, 1, 2, 9]))
+            M = max(1, min(int(rng.integers(1, 60000)), int(1.5e10 / (K * D)))) // H + 1  # the scalar witness is one thread per row
+        else:
+            D = int(rng.choice([5, 24, 32, 48, 64, 100, 128, 132, 200, 256, 260, 300, 384, 500, 512]))
+            K = int(rng.choice([1, 7, 33, 100, 256, 1000, 1024, 1100, 2048, 3000, 4100]))
+            H = int(rng.choice([1, 1, 2, 3]))
+            big = rng.random() < 0.5
+            M = int(rng.integers(140000, 300000) // H) if big else int(rng.integers(1, 40000))
+            if D > 256 and big:
+                M = int(rng.integers(33000, 70000) // H)
         metric = int(rng.integers(0, 2))
         ste = bool(rng.integers(0, 2))
         g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
@@ -50,6 +59,7 @@ while time.time() < t_end:
             print(f"MISMATCH single: H={H} M={M} K={K} D={D} metric={metric} ste={ste} grid={grid}: {bad} indices differ", flush=True)
             sys.exit(1)
         n1 += 1
+        n3 += int(wide)
     else:
         D = int(rng.choice([24, 40, 64, 100, 128, 200, 256, 300, 512]))
         K = int(rng.choice([7, 64, 100, 256, 1000]))
@@ -69,5 +79,5 @@ while time.time() < t_end:
             sys.exit(1)
         n2 += 1
     if (n1 + n2) % 20 == 0:
-        print(f"{n1} single-stage, {n2} residual configurations agree", flush=True)
-print(f"done: {n1} single-stage and {n2} residual random configurations, all bit-exact", flush=True)
+        print(f"{n1} single-stage ({n3} of them wider than 512 dims), {n2} residual configurations agree", flush=True)
+print(f"done: {n1} single-stage ({n3} wider than 512 dims) and {n2} residual random configurations, all bit-exact", flush=True)

@@ -381,7 +381,7 @@ WidePlan wide_plan(int H, long long M, int K, int D) {
     if (mc > Mp) mc = Mp;
     w.mc = mc;
     w.acc_bytes = (long long)H * mc * w.kc * 4;
-    w.xn_bytes = ((long long)H * mc * 4 + 255) / 256 * 256;
+    w.xn_bytes = 2 * (((long long)H * mc * 4 + 255) / 256 * 256);  // two buffers: a slice reads one and writes the other
     return w;
 }
 
@@ -464,7 +464,8 @@ int run_search_keys_wide(const vq_args *a, long long idx_offset, long long *keys
                 p.ws_hs = nblk * 4 * (long long)nsub * 256;
                 p.ws_nsub = nsub;
                 p.acc_in = j > 0;
-                p.xn_ws = xn_ws;
+                p.xn_ws = xn_ws + ((j + 1) & 1) * (w.xn_bytes / 8);
+                p.xn_out = xn_ws + (j & 1) * (w.xn_bytes / 8);
                 p.xn_hs = w.mc;
                 const int rc = last ? launch_wide_last(DP, p, a->H, splits, a->metric, s)
                                     : launch_wide_t<kWideSlice, 1>(p, a->H, splits, a->metric, s);
