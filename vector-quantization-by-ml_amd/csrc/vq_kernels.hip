@@ -360,7 +360,10 @@ int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipS
 // lane reads back exactly the 16-byte pieces it wrote, coalesced), and the last slice closes them with the norms and runs
 // the argmin into packed keys.  The workspace holds the chains of one (row chunk) x (code chunk) at a time.
 constexpr int kWideSlice = 512;
-constexpr long long kWideChunkBytes = 512ll << 20;  // accumulator workspace per (row chunk, code chunk)
+#ifndef VQ_EXP_WIDE_CHUNK_MB
+#define VQ_EXP_WIDE_CHUNK_MB 512
+#endif
+constexpr long long kWideChunkBytes = (long long)VQ_EXP_WIDE_CHUNK_MB << 20;  // accumulator workspace per (row chunk, code chunk)
 constexpr int kWideCodes = 4096;                    // codes per chunk
 
 struct WidePlan {
