@@ -47,6 +47,11 @@ CASES = [
         separate_codebook_per_head=False, training=True),
     _vq("mh_sep_S_train", 128, 256, (2, 64, 128), "S", heads=2, codebook_dim=64,
         separate_codebook_per_head=True, training=True),
+    # --- rows wider than 512 dims (no limit in the reference; here 512-dim slices) -----------------------
+    _vq("wide768_S", 768, 300, (2, 64, 768), "S"),
+    _vq("wide1100_R", 1100, 512, (1, 96, 1100), "R"),
+    _vq("wide640_S_train", 640, 128, (2, 40, 640), "S", training=True),
+    _vq("wide_cos_S", 600, 200, (2, 48, 600), "S", use_cosine_sim=True),
     # --- cosine similarity ---------------------------------------------------------------------------
     _vq("cos_S", 64, 512, (4, 128, 64), "S", use_cosine_sim=True),
     _vq("cos_l2_S", 64, 512, (4, 128, 64), "S", use_cosine_sim=True, transform_input="l2norm",
@@ -75,6 +80,7 @@ CASES = [
     _rvq("rvq_G", 64, 4, 256, (2, 128, 64), "G"),
     _rvq("rvq_shared", 64, 4, 256, (2, 128, 64), "S", shared_codebook=True),
     _rvq("rvq_allcodes", 32, 3, 64, (2, 20, 32), "S", return_all_codes=True),
+    _rvq("rvq_wide_S", 640, 3, 64, (2, 32, 640), "S"),
     dict(name="grvq", kind="grvq", dim=128, groups=2, Q=3, K=128, x_shape=[2, 64, 128], cls="S", training=False),
     _vq("ema_mh_shared_S", 128, 128, (4, 64, 128), "S", training=True, freeze_codebook=False, heads=2, codebook_dim=64,
         cb_extra=dict(threshold_ema_dead_code=0)),

@@ -12,7 +12,7 @@ from helpers import load_golden
 from oracle import ref_path
 
 PLAIN = ["cfg1_S", "cfg1_G", "cfg1_Gdup", "cfg2_S", "cfg2_G", "cfg2_Gdup", "k8192_S", "cos_S", "cos_G", "odd_dims",
-         "odd_small", "k1"]
+         "odd_small", "k1", "wide768_S", "wide_cos_S"]
 
 
 @pytest.mark.parametrize("name", PLAIN)
@@ -53,7 +53,7 @@ def test_exact_grid_distances(oracle, name):
     assert (ulp == 0).mean() > 0.97
 
 
-@pytest.mark.parametrize("name", ["rvq_S", "rvq_S_train", "rvq_G"])
+@pytest.mark.parametrize("name", ["rvq_S", "rvq_S_train", "rvq_G", "rvq_wide_S"])
 def test_c_oracle_rvq_equals_reference(oracle, name):
     c = CASES_BY_NAME[name]
     arrays, _ = load_golden(name)
