@@ -168,6 +168,15 @@ int vq_quantize_backward_f32(const vq_args *a, const float *grad_out, int64_t go
  */
 int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs, int64_t idx_hs,
                           const uint8_t *mask, int H, int64_t M, int K, int D, float *counts, float *sums, void *stream);
+/* Run-to-run REPRODUCIBLE variant of vq_ema_accumulate_f32 (same arguments, same meaning): no float atomics -- every
+ * (row range, code owner) pair stores its partial sums to `workspace` and a second kernel adds the row ranges in a fixed
+ * order, so two runs on the same device give bit-identical counts / sums.  workspace: >= vq_ema_det_workspace_bytes()
+ * bytes, 16-byte aligned (0 = unsupported: D > 2048).  Meant for the common "many rows per code" regime; with very many
+ * codes and few rows it is slower than the atomic path (every owner scans all indices). */
+int64_t vq_ema_det_workspace_bytes(int H, int64_t M, int K, int D);
+int vq_ema_accumulate_det_f32(const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs, int64_t idx_hs,
+                              const uint8_t *mask, int H, int64_t M, int K, int D, float *counts, float *sums, void *workspace,
+                              int64_t workspace_bytes, void *stream);
 /* The same statistics for every stage of a residual stack in one pass (residual_vq.py:212-233: stage q's Codebook sees the
  * residual r_q): uses a->x, a->cb (stages cb_qs apart; 0 = shared), a->idx (as written by vq_quantize_f32), H, M, K, D, Q
  * and VQ_F_STE (train-mode residual rule).  counts [H][Q][K], sums [H][Q][K][D], zeroed by the caller. */

@@ -52,3 +52,12 @@ for name, mod, shape in (
     t_step = timed(step)
     print(f"{name}: eval {t_eval:.3f} ms | train forward, frozen codebook {t_frozen:.3f} | train forward + EMA update {t_ema:.3f} | "
           f"forward + EMA + backward {t_step:.3f}", flush=True)
+
+# EMA accumulation alone at cfg2: float atomics vs the reproducible (atomics-free) variant
+from vector_quantization import native
+
+x = torch.randn(1, 262144, 256, device=dev)
+idx = torch.randint(0, 1024, (1, 262144), device=dev)
+t_a = timed(lambda: native.ema_accumulate(x, idx, 1024))
+t_d = timed(lambda: native.ema_accumulate(x, idx, 1024, deterministic=True))
+print(f"EMA accumulate, M=262144 K=1024 D=256 (incl. zero-fill of the outputs): atomic {t_a:.3f} ms | reproducible {t_d:.3f} ms", flush=True)

@@ -769,41 +769,58 @@ int vq_quantize_backward_f32(const vq_args *a, const float *grad_out, int64_t go
     return 0;
 }
 
+// Owner-computes launch plan: a wave owns cw codes (8 KiB of partial sums) and one of row_blocks contiguous row ranges
+struct EmaOwnerPlan {
+    int cw;
+    long long owners, row_blocks, rows_per_block;
+    size_t lds;
+};
+
+static bool ema_owner_plan(int H, long long M, int K, int D, EmaOwnerPlan &pl) {
+    if (D > 2048) return false;
+    const int D4 = (D + 3) & ~3;
+    int cw = 2048 / D4;
+    if (cw > 64) cw = 64;
+    if (cw > K) cw = K;
+    pl.cw = cw;
+    pl.owners = (K + cw - 1) / cw;
+    const DevInfo &di = dev_info();
+    const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+    long long row_blocks = (16ll * cus) / (pl.owners * H);  // ~16 waves per CU in total
+    if (row_blocks < 1) row_blocks = 1;
+    long long rows_per_block = (M + row_blocks - 1) / row_blocks;
+    if (rows_per_block < 2048) rows_per_block = 2048;
+    rows_per_block = (rows_per_block + 63) / 64 * 64;
+    pl.rows_per_block = rows_per_block;
+    pl.row_blocks = (M + rows_per_block - 1) / rows_per_block;
+    const size_t per_wave = (size_t)cw * D4 + ((cw + 3) & ~3) + 64 * 2 + 64;
+    pl.lds = per_wave * 4 * 4;
+    return true;
+}
+
+static int launch_ema_owner(const EmaOwnerPlan &pl, const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs,
+                            int64_t idx_hs, const uint8_t *mask, int H, int64_t M, int K, int D, float *counts, float *sums,
+                            float *part_sums, float *part_counts, hipStream_t s) {
+    static thread_local bool attr_done[kMaxDevices] = {};
+    if (int arc = allow_big_lds(vq_ema_accumulate_owner_kernel, attr_done)) return arc;
+    hipLaunchKernelGGL(vq_ema_accumulate_owner_kernel, dim3((unsigned)((pl.owners + 3) / 4), (unsigned)pl.row_blocks, (unsigned)H),
+                       dim3(256), pl.lds, s, x, (long long)x_rs, (long long)x_hs, (const long long *)idx, (long long)idx_rs,
+                       (long long)idx_hs, mask, (long long)M, pl.rows_per_block, K, pl.cw, D, counts, sums, part_sums, part_counts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_ema_accumulate_owner launch");
+    return 0;
+}
+
 int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs, int64_t idx_hs,
                           const uint8_t *mask, int H, int64_t M, int K, int D, float *counts, float *sums, void *stream) {
     if (H <= 0 || M < 0 || K <= 0 || D <= 0 || !counts || !sums) return fail(VQ_E_BADARG, "vq_ema_accumulate: bad argument");
     if (M == 0) return 0;
     if (!x || !idx) return fail(VQ_E_BADARG, "vq_ema_accumulate: null input");
     hipStream_t s = (hipStream_t)stream;
-    // Owner-computes path: a wave owns cw codes (8 KiB of partial sums) -- worth it when each owner sees many rows
-    if (D <= 2048) {
-        const int D4 = (D + 3) & ~3;
-        int cw = 2048 / D4;
-        if (cw > 64) cw = 64;
-        if (cw > K) cw = K;
-        const long long owners = (K + cw - 1) / cw;
-        if (M / owners >= 1024) {
-            const DevInfo &di = dev_info();
-            const int cus = di.ok && di.cus > 0 ? di.cus : 256;
-            long long row_blocks = (16ll * cus) / (owners * H);  // ~16 waves per CU in total
-            if (row_blocks < 1) row_blocks = 1;
-            long long rows_per_block = (M + row_blocks - 1) / row_blocks;
-            if (rows_per_block < 2048) rows_per_block = 2048;
-            rows_per_block = (rows_per_block + 63) / 64 * 64;
-            row_blocks = (M + rows_per_block - 1) / rows_per_block;
-            const size_t per_wave = (size_t)cw * D4 + ((cw + 3) & ~3) + 64 * 2 + 64;
-            const size_t lds = per_wave * 4 * 4;
-            static thread_local bool attr_done[kMaxDevices] = {};
-            if (int arc = allow_big_lds(vq_ema_accumulate_owner_kernel, attr_done)) return arc;
-            hipLaunchKernelGGL(vq_ema_accumulate_owner_kernel,
-                               dim3((unsigned)((owners + 3) / 4), (unsigned)row_blocks, (unsigned)H), dim3(256), lds, s, x,
-                               (long long)x_rs, (long long)x_hs, (const long long *)idx, (long long)idx_rs,
-                               (long long)idx_hs, mask, (long long)M, rows_per_block, K, cw, D, counts, sums);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return hip_fail(e, "vq_ema_accumulate_owner launch");
-            return 0;
-        }
-    }
+    // Owner-computes path: worth it when each owner sees many rows
+    EmaOwnerPlan pl;
+    if (ema_owner_plan(H, M, K, D, pl) && M / pl.owners >= 1024)
+        return launch_ema_owner(pl, x, x_rs, x_hs, idx, idx_rs, idx_hs, mask, H, M, K, D, counts, sums, nullptr, nullptr, s);
     long long blocks = (M + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(vq_ema_accumulate_kernel, dim3((unsigned)blocks, (unsigned)H), dim3(256), 0, s, x,
@@ -811,6 +828,37 @@ int vq_ema_accumulate_f32(const float *x, int64_t x_rs, int64_t x_hs, const int6
                        (long long)M, K, D, counts, sums);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "vq_ema_accumulate launch");
+    return 0;
+}
+
+int64_t vq_ema_det_workspace_bytes(int H, int64_t M, int K, int D) {
+    EmaOwnerPlan pl;
+    if (H <= 0 || M <= 0 || K <= 0 || D <= 0 || !ema_owner_plan(H, M, K, D, pl)) return 0;
+    return pl.row_blocks * H * (int64_t)K * (D + 1) * 4 + 256;
+}
+
+int vq_ema_accumulate_det_f32(const float *x, int64_t x_rs, int64_t x_hs, const int64_t *idx, int64_t idx_rs, int64_t idx_hs,
+                              const uint8_t *mask, int H, int64_t M, int K, int D, float *counts, float *sums, void *workspace,
+                              int64_t workspace_bytes, void *stream) {
+    if (H <= 0 || M < 0 || K <= 0 || D <= 0 || !counts || !sums) return fail(VQ_E_BADARG, "vq_ema_accumulate_det: bad argument");
+    if (M == 0) return 0;
+    if (!x || !idx) return fail(VQ_E_BADARG, "vq_ema_accumulate_det: null input");
+    EmaOwnerPlan pl;
+    if (!ema_owner_plan(H, M, K, D, pl)) return fail(VQ_E_UNSUPPORTED, "vq_ema_accumulate_det: D > 2048");
+    if (!workspace || workspace_bytes < vq_ema_det_workspace_bytes(H, M, K, D) || ((uintptr_t)workspace & 15))
+        return fail(VQ_E_BADARG, "vq_ema_accumulate_det: workspace too small or misaligned (see vq_ema_det_workspace_bytes)");
+    hipStream_t s = (hipStream_t)stream;
+    float *part_sums = (float *)workspace;
+    float *part_counts = part_sums + pl.row_blocks * H * (long long)K * D;
+    if (int rc = launch_ema_owner(pl, x, x_rs, x_hs, idx, idx_rs, idx_hs, mask, H, M, K, D, counts, sums, part_sums, part_counts, s))
+        return rc;
+    const long long n_s = (long long)H * K * D, n_c = (long long)H * K;
+    hipLaunchKernelGGL(vq_ema_reduce_parts_kernel, dim3((unsigned)((n_s + 255) / 256)), dim3(256), 0, s, part_sums,
+                       (int)pl.row_blocks, n_s, sums);
+    hipLaunchKernelGGL(vq_ema_reduce_parts_kernel, dim3((unsigned)((n_c + 255) / 256)), dim3(256), 0, s, part_counts,
+                       (int)pl.row_blocks, n_c, counts);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_ema_reduce_parts launch");
     return 0;
 }
 

@@ -116,6 +116,11 @@ def load():
         lib.vq_ema_accumulate_f32.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _vp, ctypes.c_int, _i64, ctypes.c_int,
                                               ctypes.c_int, _vp, _vp, _vp]
         lib.vq_ema_accumulate_f32.restype = ctypes.c_int
+        lib.vq_ema_accumulate_det_f32.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _vp, ctypes.c_int, _i64, ctypes.c_int,
+                                                  ctypes.c_int, _vp, _vp, _vp, _i64, _vp]
+        lib.vq_ema_accumulate_det_f32.restype = ctypes.c_int
+        lib.vq_ema_det_workspace_bytes.argtypes = [ctypes.c_int, _i64, ctypes.c_int, ctypes.c_int]
+        lib.vq_ema_det_workspace_bytes.restype = _i64
         lib.vq_ema_update_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_float, ctypes.c_float, ctypes.c_int, _vp]
         lib.vq_ema_update_f32.restype = ctypes.c_int
@@ -142,7 +147,8 @@ EXPORTED_SYMBOLS = (
     "vq_residual_f32", "vq_keys_init", "vq_search_keys_f32", "vq_finalize_keys_f32", "vq_last_error",
     "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32", "vq_similarities_f32", "vq_softmax_stats_f32",
     "vq_ce_backward_f32", "vq_quantize_lse_f32",
-    "vq_quantize_backward_f32", "vq_ema_accumulate_residual_f32", "vq_max_fused_stages",
+    "vq_quantize_backward_f32", "vq_ema_accumulate_residual_f32", "vq_max_fused_stages", "vq_ema_accumulate_det_f32",
+    "vq_ema_det_workspace_bytes",
 )
 
 
@@ -353,8 +359,9 @@ def finalize_keys(x: torch.Tensor, cb_full: torch.Tensor, keys: torch.Tensor, *,
     return dict(out=out, idx=idx, best=best, sq_err=sq_err)
 
 
-def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, K: int, mask: torch.Tensor | None = None):
-    """x [H, M, D] (strided rows ok), idx [H, M] int64 (any strides) -> (counts [H, K], sums [H, K, D]) fp32."""
+def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, K: int, mask: torch.Tensor | None = None, deterministic: bool = False):
+    """x [H, M, D] (strided rows ok), idx [H, M] int64 (any strides) -> (counts [H, K], sums [H, K, D]) fp32.
+    ``deterministic``: the atomics-free variant (bit-identical from run to run on one device); D <= 2048."""
     _require_gpu(x, idx)
     assert x.dtype == torch.float32 and idx.dtype == torch.int64 and x.dim() == 3 and idx.dim() == 2
     H, M, D = x.shape
@@ -367,6 +374,16 @@ def ema_accumulate(x: torch.Tensor, idx: torch.Tensor, K: int, mask: torch.Tenso
         m8 = mask.to(torch.uint8).contiguous()
         assert tuple(m8.shape) == (H, M)
     with torch.cuda.device(dev):
+        if deterministic and M > 0:
+            nbytes = int(load().vq_ema_det_workspace_bytes(H, M, K, D))
+            if nbytes == 0:
+                raise RuntimeError(f"deterministic EMA accumulation supports D <= 2048 (got D = {D})")
+            ws = torch.empty((nbytes + 15) // 16 * 2, dtype=torch.float64, device=dev)
+            _check(load().vq_ema_accumulate_det_f32(x.data_ptr(), x_rs, x_hs, idx.data_ptr(), int(idx.stride(1)),
+                                                    int(idx.stride(0)), m8.data_ptr() if m8 is not None else None, H, M, K, D,
+                                                    counts.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws.numel() * 8,
+                                                    _stream_ptr(dev)), "vq_ema_accumulate_det_f32")
+            return counts, sums
         _check(load().vq_ema_accumulate_f32(x.data_ptr(), x_rs, x_hs, idx.data_ptr(), int(idx.stride(1)), int(idx.stride(0)),
                                             m8.data_ptr() if m8 is not None else None, H, M, K, D, counts.data_ptr(),
                                             sums.data_ptr(), _stream_ptr(dev)), "vq_ema_accumulate_f32")
@@ -505,7 +522,7 @@ def quantize_backward(x: torch.Tensor, cb: torch.Tensor, idx: torch.Tensor, grad
 
 
 def ema_accumulate_residual(x: torch.Tensor, cb: torch.Tensor, idx: torch.Tensor, *, ste: bool = True,
-                            stages_share_codebook: bool = False):
+                            stages_share_codebook: bool = False, deterministic: bool = False):
     """Per-stage EMA statistics of a residual stack in one pass: x [H, M, D], cb [H, Q|1, K, D], idx [H, M, Q] ->
     (counts [H, Q, K], sums [H, Q, K, D]) where stage q accumulates the residual r_q it quantized."""
     _require_gpu(x, cb, idx)
@@ -514,6 +531,21 @@ def ema_accumulate_residual(x: torch.Tensor, cb: torch.Tensor, idx: torch.Tensor
     Hc, Qc, K, Dc = cb.shape
     Q = idx.shape[-1]
     assert Hc == H and Dc == D and (Qc == Q or (stages_share_codebook and Qc == 1))
+    if deterministic:
+        # atomics-free: one reproducible accumulation per stage on the residual that stage quantized (residual_vq.py:212-233)
+        counts, sums, r = [], [], x
+        for q in range(Q):
+            iq = idx[..., q]
+            live = iq >= 0  # dropped stages (quantize dropout) end a row's chain
+            c, s_ = ema_accumulate(r, iq, K, None if bool(live.all()) else live, deterministic=True)
+            counts.append(c)
+            sums.append(s_)
+            if q + 1 < Q:
+                code = cb[:, 0 if stages_share_codebook else q]
+                picked = torch.gather(code, 1, iq.clamp(min=0)[..., None].expand(-1, -1, D))
+                quant = r + (picked - r) if ste else picked
+                r = torch.where(live[..., None], r - quant, r)
+        return torch.stack(counts, 1), torch.stack(sums, 1)
     counts = torch.zeros((H, Q, K), dtype=torch.float32, device=x.device)
     sums = torch.zeros((H, Q, K, D), dtype=torch.float32, device=x.device)
     x_rs, x_hs = _row_strides(x)

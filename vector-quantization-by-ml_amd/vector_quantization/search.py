@@ -18,6 +18,11 @@ EUCLID = native.EUCLID
 DOT = native.DOT
 
 
+def _want_deterministic(dim: int) -> bool:
+    """torch.use_deterministic_algorithms(True) selects the reproducible EMA accumulation (rows of up to 2048 dims)."""
+    return torch.are_deterministic_algorithms_enabled() and dim <= 2048
+
+
 class _NativeBackend:
     name = "hip-gfx950"
     accepts_half_rows = True  # fp16 / bf16 rows are widened in the kernel's prologue (inference launches)
@@ -91,13 +96,15 @@ class _NativeBackend:
 
     @staticmethod
     def ema_accumulate(x, idx, k, mask=None):
-        """-> (counts [H, K], sums [H, K, D]) of the rows assigned to each code (vq_ema_accumulate_f32)."""
-        return native.ema_accumulate(x, idx, k, mask)
+        """-> (counts [H, K], sums [H, K, D]) of the rows assigned to each code (vq_ema_accumulate_f32; under
+        torch.use_deterministic_algorithms(True) the atomics-free vq_ema_accumulate_det_f32)."""
+        return native.ema_accumulate(x, idx, k, mask, deterministic=_want_deterministic(x.shape[-1]))
 
     @staticmethod
     def ema_accumulate_residual(x, cb, idx, *, ste, share):
         """-> (counts [H, Q, K], sums [H, Q, K, D]) for every stage of a residual stack (vq_ema_accumulate_residual_f32)."""
-        return native.ema_accumulate_residual(x, cb, idx, ste=ste, stages_share_codebook=share)
+        return native.ema_accumulate_residual(x, cb, idx, ste=ste, stages_share_codebook=share,
+                                              deterministic=_want_deterministic(x.shape[-1]))
 
     @staticmethod
     def ema_update(cluster_size, embed_avg, embeddings, hits, sums, *, decay, eps, l2norm):
