@@ -46,7 +46,7 @@ extern "C" {
  * K codes x D dims:  Kp = roundup(K, 32) rows of (Dp + 4) floats, Dp = padded dim chosen by the library
  * (32/64/128/256/512); inside each group of 8 dims the even dims come first, then the odd ones, values
  * pre-scaled by -2 (Euclid) or 1 (dot); float Dp of each row holds |c|^2 (d-ordered fmaf chain).
- * D > 512: ceil(D / 512) such images of Dp = 512 back to back, one per 512-dim slice of the rows.
+ * D > 512: ceil(D / 256) such images back to back, one per 256-dim slice of the rows (the last one as wide as it needs).
  * Returns the number of floats ONE packed codebook occupies (including over-copy slack), 0 on bad args.
  */
 int64_t vq_packed_floats(int K, int D);
@@ -97,7 +97,7 @@ int64_t vq_workspace_bytes(int H, int64_t M, int Q);
 /*
  * The same for rows WIDER than 512 dims (Q == 1).  The reference has no limit on the row width (cdist / einsum over any
  * D, codebooks.py:122-129,386); here a distance is one k-ordered fmaf chain over all dims, so such rows are swept in
- * 512-dim slices and the chains of one (row chunk) x (code chunk) wait in the workspace between two slices
+ * 256-dim slices and the chains of one (row chunk) x (code chunk) wait in the workspace between two slices
  * (at most 512 MiB beyond vq_workspace_bytes(H, M, 1)).  For D <= 512 this is vq_workspace_bytes(H, M, 1).
  */
 int64_t vq_workspace_bytes_wide(int H, int64_t M, int K, int D);

@@ -356,10 +356,15 @@ int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipS
 
 // ---- rows wider than 512 dims -------------------------------------------------------------------
 // The distance of a (row, code) pair is ONE k-ordered fmaf chain over all dims, so the sweep is cut along d into slices of
-// 512 dims: slice j continues the chains slice j - 1 left in the workspace (the accumulators' own fragment layout: every
+// kWideSlice dims: slice j continues the chains slice j - 1 left in the workspace (the accumulators' own fragment layout: every
 // lane reads back exactly the 16-byte pieces it wrote, coalesced), and the last slice closes them with the norms and runs
 // the argmin into packed keys.  The workspace holds the chains of one (row chunk) x (code chunk) at a time.
-constexpr int kWideSlice = 512;
+#ifndef VQ_EXP_WIDE_SLICE
+#define VQ_EXP_WIDE_SLICE 256
+#endif
+constexpr int kWideSlice = VQ_EXP_WIDE_SLICE;                // dims per slice: 512 (4-wave workgroups) or 256 (8-wave)
+constexpr int kWideWaves = kWideSlice == 512 ? 4 : 8;
+constexpr int kWideRows = 32 * kWideWaves;                   // rows per workgroup
 #ifndef VQ_EXP_WIDE_CHUNK_MB
 #define VQ_EXP_WIDE_CHUNK_MB 512
 #endif
@@ -367,7 +372,7 @@ constexpr long long kWideChunkBytes = (long long)VQ_EXP_WIDE_CHUNK_MB << 20;  //
 constexpr int kWideCodes = 4096;                    // codes per chunk
 
 struct WidePlan {
-    int nd;            // 512-dim slices
+    int nd;            // slices
     int kc;            // codes per chunk (multiple of 32)
     long long mc;      // rows per chunk (multiple of 128)
     long long acc_bytes, xn_bytes;
@@ -378,9 +383,9 @@ WidePlan wide_plan(int H, long long M, int K, int D) {
     w.nd = (D + kWideSlice - 1) / kWideSlice;
     const int Kp = round_up(K, kTileCodes);
     w.kc = Kp < kWideCodes ? Kp : kWideCodes;
-    const long long Mp = (M + 127) / 128 * 128;
-    long long mc = kWideChunkBytes / ((long long)H * w.kc * 4) / 128 * 128;
-    if (mc < 128) mc = 128;
+    const long long Mp = (M + kWideRows - 1) / kWideRows * kWideRows;
+    long long mc = kWideChunkBytes / ((long long)H * w.kc * 4) / kWideRows * kWideRows;
+    if (mc < kWideRows) mc = kWideRows;
     if (mc > Mp) mc = Mp;
     w.mc = mc;
     w.acc_bytes = (long long)H * mc * w.kc * 4;
@@ -389,7 +394,7 @@ WidePlan wide_plan(int H, long long M, int K, int D) {
 }
 
 long long wide_image_floats(int K) { return (long long)round_up(K, kTileCodes) * (kWideSlice + 4) + kPackSlack; }
-// the last slice is padded like a narrow row of its own width (32 ... 512 dims) and packed in that layout
+// the last slice is padded like a narrow row of its own width (32 ... kWideSlice dims) and packed in that layout
 int wide_last_dims(int D) { return D - (D - 1) / kWideSlice * kWideSlice; }
 long long wide_last_image_floats(int K, int D) {
     const int DP = padded_dim(wide_last_dims(D));
@@ -398,8 +403,8 @@ long long wide_last_image_floats(int K, int D) {
 
 template <int DP, int WIDE>
 int launch_wide_t(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
-    if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, 4, VQ_METRIC_EUCLID, 0, false, 0, WIDE>(p, H, splits, s);
-    return launch_search_t<DP, 4, VQ_METRIC_DOT, 0, false, 0, WIDE>(p, H, splits, s);
+    if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, kWideWaves, VQ_METRIC_EUCLID, 0, false, 0, WIDE>(p, H, splits, s);
+    return launch_search_t<DP, kWideWaves, VQ_METRIC_DOT, 0, false, 0, WIDE>(p, H, splits, s);
 }
 
 int launch_wide_last(int DP, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
@@ -408,7 +413,9 @@ int launch_wide_last(int DP, const SearchParams &p, int H, int splits, int metri
         case 64: return launch_wide_t<64, 2>(p, H, splits, metric, s);
         case 128: return launch_wide_t<128, 2>(p, H, splits, metric, s);
         case 256: return launch_wide_t<256, 2>(p, H, splits, metric, s);
-        case 512: return launch_wide_t<512, 2>(p, H, splits, metric, s);
+        case 512:
+            if constexpr (kWideSlice == 512) return launch_wide_t<512, 2>(p, H, splits, metric, s);
+            break;
     }
     return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
 }
@@ -430,7 +437,7 @@ int run_search_keys_wide(const vq_args *a, long long idx_offset, long long *keys
     const int d_last = wide_last_dims(a->D), dp_last = padded_dim(d_last);
     for (long long m0 = 0; m0 < a->M; m0 += w.mc) {
         const long long mrows = (a->M - m0 < w.mc) ? a->M - m0 : w.mc;
-        const long long nblk = (mrows + 127) / 128;
+        const long long nblk = (mrows + kWideRows - 1) / kWideRows;
         for (int k0 = 0; k0 < Kp; k0 += w.kc) {
             const int kcodes = (a->K - k0 < w.kc) ? a->K - k0 : w.kc;  // real codes of this chunk (> 0: k0 < Kp, K > Kp - 32)
             const int nsub = (kcodes + kTileCodes - 1) / kTileCodes;
@@ -449,8 +456,8 @@ int run_search_keys_wide(const vq_args *a, long long idx_offset, long long *keys
                 p.M = mrows; p.K = kcodes; p.D = last ? d_last : kWideSlice; p.Q = 1;
                 const int tc = kTileCodes * sub_tiles(DP);
                 p.ntiles = (kcodes + tc - 1) / tc;
-                // K is split over workgroups until the chip is full (one 4-wave workgroup per CU at Dp = 512, two below)
-                const long long fill = (long long)cus * (DP == 512 ? 1 : 2);
+                // K is split over workgroups until the chip is full (one workgroup per CU at Dp = 512 / 8 waves at Dp = 256)
+                const long long fill = (long long)cus * ((DP == 512 || (kWideWaves == 8 && DP == 256)) ? 1 : 2);
                 int splits = 1;
                 if (nblk * a->H < fill) {
                     splits = (int)((fill + nblk * a->H - 1) / (nblk * a->H));
@@ -464,7 +471,7 @@ int run_search_keys_wide(const vq_args *a, long long idx_offset, long long *keys
                 p.idx_offset = idx_offset + k0;
                 p.vec_x = (p.D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x)) ? 1 : 0;
                 p.acc_ws = acc_ws;
-                p.ws_hs = nblk * 4 * (long long)nsub * 256;
+                p.ws_hs = nblk * kWideWaves * (long long)nsub * 256;
                 p.ws_nsub = nsub;
                 p.acc_in = j > 0;
                 p.xn_ws = xn_ws + ((j + 1) & 1) * (w.xn_bytes / 8);
@@ -554,7 +561,7 @@ int vq_device_info(char *buf, size_t n) {
 int64_t vq_packed_floats(int K, int D) {
     if (K <= 0 || D <= 0) return 0;
     const int DP = padded_dim(D);
-    if (DP == 0)  // one image per 512-dim slice, the last one in the layout of its own (padded) width
+    if (DP == 0)  // one image per slice, the last one in the layout of its own (padded) width
         return (int64_t)((D - 1) / kWideSlice) * wide_image_floats(K) + wide_last_image_floats(K, D);
     return (int64_t)round_up(K, kTileCodes * sub_tiles(DP)) * (DP + 4) + kPackSlack;
 }
@@ -580,7 +587,7 @@ int vq_pack_codebooks_f32(const float *cb, int n_codebooks, int64_t cb_stride, i
     if (!aligned16(packed)) return fail(VQ_E_BADARG, "vq_pack: packed buffer must be 16-byte aligned");
     const long long pk_stride = vq_packed_floats(K, D);
     hipStream_t s = (hipStream_t)stream;
-    if (DP == 0) {  // rows wider than 512 dims: one image per 512-dim slice
+    if (DP == 0) {  // rows wider than 512 dims: one image per slice
         const int nd = (D + kWideSlice - 1) / kWideSlice;
         for (int j = 0; j < nd; ++j) {
             const int dp = (j + 1 == nd) ? padded_dim(wide_last_dims(D)) : kWideSlice;

@@ -204,7 +204,7 @@ def pack_codebooks(cb: torch.Tensor, metric: int) -> torch.Tensor:
 
 def _workspace(H: int, M: int, Q: int, device, K: int = 0, D: int = 0) -> torch.Tensor:
     nbytes = int(load().vq_workspace_bytes(H, M, Q))
-    if D > 512:  # rows wider than 512 dims: room for the distance chains carried between the 512-dim slices
+    if D > 512:  # rows wider than 512 dims: room for the distance chains carried between the slices of the sweep
         nbytes = max(nbytes, int(load().vq_workspace_bytes_wide(H, M, K, D)))
     return torch.empty((nbytes + 15) // 16 * 2, dtype=torch.float64, device=device)
 
