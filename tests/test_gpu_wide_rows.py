@@ -188,3 +188,29 @@ def test_wide_rows_modules(oracle):
         q, i, _ = mod(xin.to(DEV))
         assert torch.equal(i.cpu(), ri)
         torch.testing.assert_close(q.cpu(), rq, rtol=0, atol=1e-6)
+
+
+def test_wide_rows_graph_replay_and_compile():
+    """The multi-launch sequence of a wide-row forward is capturable (no host synchronisation, workspace from the capture's
+    pool) and traceable (torch.compile goes through torch.ops.vq_mi355x.quantize_into like the narrow path)."""
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(0)
+    mod = vq.VectorQuantize(dim=768, codebook_params=CodebookParams(dim=768, codebook_size=300)).to(DEV).eval()
+    fast = vq.GraphedForward(mod, torch.randn(4, 200, 768, device=DEV))
+    for step in range(3):
+        if step == 2:
+            with torch.no_grad():
+                mod._codebook.embeddings.copy_(torch.randn_like(mod._codebook.embeddings))
+        x = torch.randn(4, 200, 768, device=DEV)
+        q, i, _ = fast(x)
+        with torch.no_grad():
+            q_ref, i_ref, _ = mod(x)
+        assert torch.equal(i, i_ref) and torch.equal(q, q_ref)
+    cmod = torch.compile(mod, fullgraph=True)
+    x = torch.randn(4, 200, 768, device=DEV)
+    with torch.no_grad():
+        q, i, _ = cmod(x)
+        q_ref, i_ref, _ = mod(x)
+    assert torch.equal(i, i_ref) and torch.equal(q, q_ref)
