@@ -124,7 +124,7 @@ int vq_nearest_f32(const vq_args *a, void *stream);
 int vq_residual_f32(const vq_args *a, void *stream);
 
 /* Largest number of residual stages ONE fused launch can hold for rows of dimension D (the winners' indices and, with
- * want_sq_err, the loss partials of every stage live in the CU's 160 KiB of LDS).  0 when D has no MFMA path (D > 512).
+ * want_sq_err, the loss partials of every stage live in the CU's 160 KiB of LDS).  0 for D > 512 (such rows are searched one stage per call, in 256-dim slices).
  * A caller with more stages (the reference's ResidualVQ has no limit, residual_vq.py:212-243) runs its layers one
  * launch each instead.  Host-side arithmetic only: no device call. */
 int vq_max_fused_stages(int D, int want_sq_err);

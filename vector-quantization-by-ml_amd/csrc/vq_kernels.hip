@@ -999,7 +999,7 @@ int vq_ce_backward_f32(const vq_args *a, const float *lse, const float *target_l
 }
 
 int vq_max_fused_stages(int D, int want_sq_err) {
-    // largest Q one residual launch can hold (winner indices and loss partials of every stage live in LDS); 0: no MFMA path
+    // largest Q one residual launch can hold (winner indices and loss partials of every stage live in LDS); 0: no fused residual launch (D > 512)
     switch (padded_dim(D)) {
         case 32: return max_stages_t<32, 8>(want_sq_err != 0);
         case 64: return max_stages_t<64, 8>(want_sq_err != 0);
