@@ -444,3 +444,21 @@ def test_non_finite_rows_do_not_disturb_their_neighbours():
         keep[[5, 77, 1000]] = False
         assert torch.equal(idx[keep], clean["idx"][0, :, 0][keep])
         assert torch.equal(r["out"][0][keep], clean["out"][0][keep])
+
+
+@pytest.mark.parametrize("M,K,D", [(1_200_000, 64, 1024), (9_000_000, 40, 256)])
+def test_inputs_beyond_2_31_elements(M, K, D):
+    """Row offsets past 2^31 elements (9.2 GB of rows; 4.9 GB of wide rows through several row chunks): every pointer offset
+    in the launchers and kernels is 64-bit.  Checked against the one-thread-per-row kernel on every row."""
+    native = _native()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn((1, M, D), device=DEV, generator=g)
+    cb = torch.randn((1, 1, K, D), device=DEV, generator=g)
+    a = native.quantize(x, cb)
+    s = native.quantize(x, cb, flags=native.F_FORCE_SIMPLE)
+    torch.cuda.synchronize()
+    assert torch.equal(a["idx"], s["idx"])
+    assert torch.equal(a["best"].view(torch.int32), s["best"].view(torch.int32))
+    assert torch.equal(a["out"], s["out"])
+    del x, a, s
+    torch.cuda.empty_cache()
