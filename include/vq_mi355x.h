@@ -189,7 +189,8 @@ int vq_ema_update_f32(float *cluster_size, float *embed_avg, float *embeddings, 
  * H, M, K, D, metric; Q is ignored.
  * vq_similarities_f32: sims[h*sims_hs + m*sims_rs + k] = -cdist(x, c) (Euclid) or x.c (dot): the third return value of
  *   Codebook.forward -- codebooks.py:386,435 -- bit-identical to the values the search compares.  The caller chooses
- *   how many rows to materialise at once (row chunks via the x / sims pointers).
+ *   how many rows to materialise at once (row chunks via the x / sims pointers).  Rows wider than 512 dims run the sliced
+ *   MFMA sweep when a->workspace holds vq_workspace_bytes_wide(H, M, K, D) bytes, else one thread per entry.
  * vq_softmax_stats_f32: logits = scale * similarity; lse[h*M + m] = log sum_k exp(logit), target_logit[h*M + m] = logit
  *   of code target[h*tgt_hs + m*tgt_rs] (0 for a negative = ignored target; -inf for one >= K).  This is
  *   F.cross_entropy(distances, codes, ignore_index=-1) -- vector_quantize_pytorch.py:287-297 -- as an online-softmax

@@ -214,3 +214,27 @@ def test_wide_rows_graph_replay_and_compile():
         q, i, _ = cmod(x)
         q_ref, i_ref, _ = mod(x)
     assert torch.equal(i, i_ref) and torch.equal(q, q_ref)
+
+
+@pytest.mark.parametrize("H,M,K,D", [(1, 300, 1000, 520), (2, 100, 64, 640), (1, 77, 4100, 516), (1, 5000, 96, 768),
+                                     (3, 70, 7, 1537), (1, 40000, 33, 600)])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_wide_rows_similarities_bit_exact(oracle, H, M, K, D, metric):
+    """The similarity matrix (third return value of Codebook.forward, codebooks.py:386,435) at D > 512: the sliced sweep whose
+    last slice writes -sqrt / dot instead of reducing.  Equal to the scalar kernel on every entry, to the oracle's winning
+    values where the search looks, and the row argmax is the search's index."""
+    native = _native()
+    g = torch.Generator().manual_seed(M + K + D)
+    x = torch.randn((H, M, D), generator=g).to(DEV)
+    cb = torch.randn((H, K, D), generator=g).to(DEV)
+    sims = native.similarities(x, cb, metric=metric)
+    ref = native.similarities(x, cb, metric=metric, flags=native.F_FORCE_SIMPLE)
+    assert torch.equal(sims.view(torch.int32), ref.view(torch.int32))
+    r = native.quantize(x, cb[:, None].contiguous(), metric=metric)
+    best = sims.max(dim=-1).values
+    want = -r["best"][..., 0] if metric == 0 else r["best"][..., 0]
+    assert torch.equal(best.view(torch.int32), want.view(torch.int32))
+    # strided destination (a column window of a wider matrix)
+    wide = torch.full((H, M, K + 8), 7.0, device=DEV)
+    native.similarities(x, cb, metric=metric, out=wide[..., 4:4 + K])
+    assert torch.equal(wide[..., 4:4 + K], sims) and bool((wide[..., :4] == 7).all()) and bool((wide[..., 4 + K:] == 7).all())

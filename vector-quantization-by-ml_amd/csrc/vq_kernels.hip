@@ -407,20 +407,28 @@ int launch_wide_t(const SearchParams &p, int H, int splits, int metric, hipStrea
     return launch_search_t<DP, kWideWaves, VQ_METRIC_DOT, 0, false, 0, WIDE>(p, H, splits, s);
 }
 
+template <int WIDE>
 int launch_wide_last(int DP, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
     switch (DP) {
-        case 32: return launch_wide_t<32, 2>(p, H, splits, metric, s);
-        case 64: return launch_wide_t<64, 2>(p, H, splits, metric, s);
-        case 128: return launch_wide_t<128, 2>(p, H, splits, metric, s);
-        case 256: return launch_wide_t<256, 2>(p, H, splits, metric, s);
+        case 32: return launch_wide_t<32, WIDE>(p, H, splits, metric, s);
+        case 64: return launch_wide_t<64, WIDE>(p, H, splits, metric, s);
+        case 128: return launch_wide_t<128, WIDE>(p, H, splits, metric, s);
+        case 256: return launch_wide_t<256, WIDE>(p, H, splits, metric, s);
         case 512:
-            if constexpr (kWideSlice == 512) return launch_wide_t<512, 2>(p, H, splits, metric, s);
+            if constexpr (kWideSlice == 512) return launch_wide_t<512, WIDE>(p, H, splits, metric, s);
             break;
     }
     return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
 }
 
-int run_search_keys_wide(const vq_args *a, long long idx_offset, long long *keys, hipStream_t s) {
+bool wide_workspace_ok(const vq_args *a) {
+    const WidePlan w = wide_plan(a->H, a->M, a->K, a->D);
+    return a->workspace && a->workspace_bytes >= vq_workspace_bytes(a->H, a->M, 1) + w.acc_bytes + w.xn_bytes;
+}
+
+// `keys` (search: argmin into packed keys) or `sims` (the similarity matrix itself) -- exactly one of them
+int run_wide(const vq_args *a, long long idx_offset, long long *keys, float *sims, long long sims_rs, long long sims_hs,
+             hipStream_t s) {
     if (!a->packed) return fail(VQ_E_BADARG, "vq: packed codebook is null");
     if (a->flags & (VQ_F_X_F16 | VQ_F_X_BF16)) return fail(VQ_E_UNSUPPORTED, "vq: 2-byte rows need D <= 512");
     const long long img = wide_image_floats(a->K);
@@ -466,7 +474,7 @@ int run_search_keys_wide(const vq_args *a, long long idx_offset, long long *keys
                 p.tiles_per_split = (p.ntiles + splits - 1) / splits;
                 splits = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
                 p.mode = kModeKeys;
-                p.keys = keys + m0;
+                p.keys = keys ? keys + m0 : nullptr;
                 p.key_hs = a->M;
                 p.idx_offset = idx_offset + k0;
                 p.vec_x = (p.D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x)) ? 1 : 0;
@@ -477,8 +485,14 @@ int run_search_keys_wide(const vq_args *a, long long idx_offset, long long *keys
                 p.xn_ws = xn_ws + ((j + 1) & 1) * (w.xn_bytes / 8);
                 p.xn_out = xn_ws + (j & 1) * (w.xn_bytes / 8);
                 p.xn_hs = w.mc;
-                const int rc = last ? launch_wide_last(DP, p, a->H, splits, a->metric, s)
-                                    : launch_wide_t<kWideSlice, 1>(p, a->H, splits, a->metric, s);
+                if (sims) {
+                    p.sims = sims + m0 * sims_rs + k0;
+                    p.sims_rs = sims_rs; p.sims_hs = sims_hs;
+                    p.vec_s = (a->K % 4 == 0 && sims_rs % 4 == 0 && sims_hs % 4 == 0 && aligned16(sims)) ? 1 : 0;
+                }
+                const int rc = !last ? launch_wide_t<kWideSlice, 1>(p, a->H, splits, a->metric, s)
+                               : sims ? launch_wide_last<3>(DP, p, a->H, splits, a->metric, s)
+                                      : launch_wide_last<2>(DP, p, a->H, splits, a->metric, s);
                 if (rc) return rc;
             }
         }
@@ -488,7 +502,7 @@ int run_search_keys_wide(const vq_args *a, long long idx_offset, long long *keys
 
 int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hipStream_t s) {
     const int DP = padded_dim(a->D);
-    if (DP == 0 && !(a->flags & VQ_F_FORCE_SIMPLE)) return run_search_keys_wide(a, idx_offset, keys, s);
+    if (DP == 0 && !(a->flags & VQ_F_FORCE_SIMPLE)) return run_wide(a, idx_offset, keys, nullptr, 0, 0, s);
     const bool simple = (a->flags & VQ_F_FORCE_SIMPLE) || DP == 0;
     if (simple) {
         if (!a->cb) return fail(VQ_E_BADARG, "vq: natural codebook required for the scalar kernel");
@@ -923,6 +937,10 @@ int vq_similarities_f32(const vq_args *a, float *sims, int64_t sims_rs, int64_t 
     if (!sims) return fail(VQ_E_BADARG, "vq_similarities: sims is null");
     hipStream_t s = (hipStream_t)stream;
     const int DP = padded_dim(a->D);
+    // rows wider than 512 dims: the sliced MFMA sweep when the caller provides its workspace (vq_workspace_bytes_wide),
+    // else the one-thread-per-entry kernel
+    if (DP == 0 && !(a->flags & VQ_F_FORCE_SIMPLE) && a->packed && wide_workspace_ok(a))
+        return run_wide(a, 0, nullptr, sims, sims_rs, sims_hs, s);
     if ((a->flags & VQ_F_FORCE_SIMPLE) || DP == 0) {
         if (!a->cb) return fail(VQ_E_BADARG, "vq_similarities: natural codebook required for the scalar kernel");
         const long long n = a->M * (long long)a->K;

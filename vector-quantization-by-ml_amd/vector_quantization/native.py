@@ -432,6 +432,9 @@ def similarities(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, pac
     if out is None:
         out = torch.empty((H, M, K), dtype=torch.float32, device=x.device)
     assert out.dtype == torch.float32 and tuple(out.shape) == (H, M, K) and (K == 1 or out.stride(2) == 1)
+    if a.D > 512 and not (flags & F_FORCE_SIMPLE):  # rows wider than 512 dims: the sliced sweep needs its workspace
+        ws = _workspace(H, M, 1, x.device, K, a.D)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8
     with torch.cuda.device(x.device):
         _check(load().vq_similarities_f32(ctypes.byref(a), out.data_ptr(), int(out.stride(1)), int(out.stride(0)),
                                           _stream_ptr(x.device)), "vq_similarities_f32")
