@@ -374,7 +374,7 @@ constexpr int kWideCodes = 4096;                    // codes per chunk
 struct WidePlan {
     int nd;            // slices
     int kc;            // codes per chunk (multiple of 32)
-    long long mc;      // rows per chunk (multiple of 128)
+    long long mc;      // rows per chunk (multiple of kWideRows)
     long long acc_bytes, xn_bytes;
 };
 
