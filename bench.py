@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- vectors quantized / second on the nearest-codebook hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|k8192|cfg3a|cfg3b|cfg4|cfg1] [--legs a,b,...]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|k8192|cfg3a|cfg3b|cfg4|cfg1|wide1024] [--legs a,b,...]
 
 N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
 (one rank per GPU, RCCL).  A "step" is one full eval-mode module forward (fused search/gather launch; the packed
@@ -20,7 +20,8 @@ Objects in the JSON line beside the contract's keys:
                 sample, rank 0 / N = 1 only; also the 1-thread figure and the CPU model.
   legs          (N = 1) the other single-GPU BASELINE workloads, each run like the headline (same W / K): k8192
                 (north-star roofline shape), cfg3a / cfg3b (multi-head, per-head dim 64 / 512), cfg4 (ResidualVQ) --
-                value, ms_per_step, roofline and a CPU-oracle parity gate per leg.
+                value, ms_per_step, roofline and a CPU-oracle parity gate per leg; plus wide1024 (rows of 1024 dims:
+                not a BASELINE config, the sliced sweep for rows wider than one launch holds).
   sharded_k65536  BASELINE configs[4]: K = 65536, D = 512 sharded over the N ranks (packed-key MIN all-reduce or
                 one-hop all-gather + local min); at N = 1 the full-codebook 1-GPU figure of the same kernels.
 """
@@ -57,8 +58,13 @@ WORKLOADS = {
     "cfg4": dict(kind="rvq", dim=256, K=1024, Q=8, x_shape=(64, 1024, 256),
                  desc="ResidualVQ num_quantizers=8 codebook_size=1024 dim=256, batch [64,1024,256] per GPU, eval"),
     "cfg1": dict(kind="vq", dim=64, K=256, x_shape=(32, 256, 64), desc="VectorQuantize dim=64 codebook_size=256, batch [32,256,64], eval"),
+    # not a BASELINE config: rows wider than the 512 dims one launch holds (the reference has no width limit); the search is a
+    # sequence of launches here (256-dim slices, chains carried through the workspace, then the finalize), timed as one
+    "wide1024": dict(kind="vq", dim=1024, K=1024, x_shape=(64, 1024, 1024),
+                     desc="VectorQuantize dim=1024 codebook_size=1024, batch [64,1024,1024] per GPU, eval (rows wider than 512 dims: "
+                          "sliced sweep; roofline = the whole launch sequence of one search)"),
 }
-DEFAULT_LEGS = "k8192,cfg3a,cfg3b,cfg4"
+DEFAULT_LEGS = "k8192,cfg3a,cfg3b,cfg4,wide1024"
 
 
 def log(*a):
@@ -303,7 +309,8 @@ def run_workload(name, args, device, rank, world, want_parity):
     ab = algorithmic_bytes_per_step(w)
     roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic_record(name),
-                kernel=("vq_search_pair512" if (head_dim(w) > 256 and w.get("Q", 1) == 1) else
+                kernel=("vq_search_mfma<256, 8, .., WIDE> x slices + vq_finalize_kernel" if head_dim(w) > 512 else
+                        "vq_search_pair512" if (head_dim(w) > 256 and w.get("Q", 1) == 1) else
                         "vq_search_persist" if (128 < head_dim(w) <= 256 and w.get("Q", 1) == 1 and 1024 <= w["K"] <= 3072) else
                         "vq_search_mfma"),
                 kernel_ms=round(live_ms, 4), kernel_ms_isolated=round(iso_ms, 4), launches_timed=len(kernel_events),
