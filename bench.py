@@ -309,7 +309,7 @@ def run_workload(name, args, device, rank, world, want_parity):
     ab = algorithmic_bytes_per_step(w)
     roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic_record(name),
-                kernel=("vq_search_mfma<256, 8, .., WIDE> x slices + vq_finalize_kernel" if head_dim(w) > 512 else
+                kernel=("vq_search_mfma<256, 8, .., WIDE> x slices (the last one finishes the call)" if head_dim(w) > 512 else
                         "vq_search_pair512" if (head_dim(w) > 256 and w.get("Q", 1) == 1) else
                         "vq_search_persist" if (128 < head_dim(w) <= 256 and w.get("Q", 1) == 1 and 1024 <= w["K"] <= 3072) else
                         "vq_search_mfma"),

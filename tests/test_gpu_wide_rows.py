@@ -81,6 +81,8 @@ def test_wide_rows_training_outputs(oracle, H, M, K, D, metric):
     (2, 9000, 5000, 777, 1),
     (1, 1460, 5000, 2056, 0),   # five slices, K split 22 ways, two code chunks: the |x|^2 chain is read and written by every split
     (1, 20000, 1000, 1600, 0),
+    (2, 40000, 1000, 768, 0),   # enough row blocks and one code chunk: the last slice finishes the inference call itself
+    (1, 66000, 64, 520, 1),     # (no keys, no finalize kernel), also with a ragged last row block
 ])
 def test_wide_rows_chunked_equals_scalar_kernel(oracle, H, M, K, D, metric):
     native = _native()

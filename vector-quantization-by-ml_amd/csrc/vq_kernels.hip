@@ -426,9 +426,23 @@ bool wide_workspace_ok(const vq_args *a) {
     return a->workspace && a->workspace_bytes >= vq_workspace_bytes(a->H, a->M, 1) + w.acc_bytes + w.xn_bytes;
 }
 
-// `keys` (search: argmin into packed keys) or `sims` (the similarity matrix itself) -- exactly one of them
+// One (row chunk, code chunk) covers all codes and every launch fills the chip without a K split: the last slice can finish
+// the inference call itself (idx, best, out = codebook[idx]) instead of going through keys and the finalize kernel.
+bool wide_fusable(const vq_args *a) {
+    if (a->Q != 1 || (a->flags & (VQ_F_STE | VQ_F_FORCE_SPLIT | VQ_F_FORCE_SIMPLE)) || a->sq_err || !a->out || !a->idx || !a->cb)
+        return false;
+    if (a->D % 4 || a->out_rs % 4 || a->out_hs % 4 || !aligned16(a->out) || a->cb_hs % 4 || !aligned16(a->cb)) return false;
+    if (round_up(a->K, kTileCodes) > kWideCodes) return false;
+    const DevInfo &di = dev_info();
+    const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+    const WidePlan w = wide_plan(a->H, a->M, a->K, a->D);
+    const long long last_rows = a->M % w.mc ? a->M % w.mc : w.mc;  // the smallest row chunk
+    return ((last_rows + kWideRows - 1) / kWideRows) * a->H >= cus;
+}
+
+// `keys` (search: argmin into packed keys), `sims` (the similarity matrix itself) or `fused` (the whole inference call)
 int run_wide(const vq_args *a, long long idx_offset, long long *keys, float *sims, long long sims_rs, long long sims_hs,
-             hipStream_t s) {
+             hipStream_t s, bool fused = false) {
     if (!a->packed) return fail(VQ_E_BADARG, "vq: packed codebook is null");
     if (a->flags & (VQ_F_X_F16 | VQ_F_X_BF16)) return fail(VQ_E_UNSUPPORTED, "vq: 2-byte rows need D <= 512");
     const long long img = wide_image_floats(a->K);
@@ -473,7 +487,16 @@ int run_wide(const vq_args *a, long long idx_offset, long long *keys, float *sim
                 }
                 p.tiles_per_split = (p.ntiles + splits - 1) / splits;
                 splits = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
-                p.mode = kModeKeys;
+                p.mode = fused ? kModeFused : kModeKeys;
+                if (fused) {
+                    p.cb = a->cb; p.cb_hs = a->cb_hs;
+                    p.out = a->out + m0 * a->out_rs; p.out_rs = a->out_rs; p.out_hs = a->out_hs;
+                    p.idx = (long long *)a->idx + m0 * a->idx_rs; p.idx_rs = a->idx_rs; p.idx_hs = a->idx_hs;
+                    p.best = a->best ? a->best + m0 * a->idx_rs : nullptr;
+                    p.fin_D = a->D;
+                    splits = 1;
+                    p.tiles_per_split = p.ntiles;
+                }
                 p.keys = keys ? keys + m0 : nullptr;
                 p.key_hs = a->M;
                 p.idx_offset = idx_offset + k0;
@@ -738,6 +761,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         return 0;
     }
 
+    if (DP == 0 && wide_fusable(a)) return run_wide(a, 0, nullptr, nullptr, 0, 0, s, true);
     if (a->Q != 1) return fail(VQ_E_UNSUPPORTED, "vq_quantize: residual stages need the MFMA kernel (D <= 512)");
     if ((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err)
         return fail(VQ_E_UNSUPPORTED, "vq_quantize: per-head squared errors need the MFMA kernel (D <= 512)");
