@@ -75,6 +75,16 @@ def forward_cases():
     cases.append(("VectorQuantize", dict(dim=32, codebook_diversity_loss_weight=0.2, codebook_diversity_temperature=3.0,
                                          cb=dict(dim=32, codebook_size=40, use_cosine_sim=True, transform_input="l2norm",
                                                  weights_regularization="l2norm", **noexp)), (2, 30, 32), {}))
+    # rows wider than 512 dims (no width limit in the reference; sliced sweep on the device) -- incl. the losses
+    # whose fused kernels stop at 512 dims and fall back to row chunks of the similarity matrix there
+    wide = dict(dim=640, codebook_size=40, **noexp)
+    cases.append(("VectorQuantize", dict(dim=640, cb=dict(wide)), (2, 30, 640), {}))
+    cases.append(("VectorQuantize", dict(dim=640, cb=dict(wide)), (2, 30, 640), dict(mask=True)))
+    cases.append(("VectorQuantize", dict(dim=640, commitment_use_cross_entropy_loss=True, cb=dict(wide)), (2, 30, 640), {}))
+    cases.append(("VectorQuantize", dict(dim=640, codebook_diversity_loss_weight=0.3, codebook_diversity_temperature=2.0,
+                                         cb=dict(wide)), (2, 30, 640), {}))
+    cases.append(("VectorQuantize", dict(dim=600, cb=dict(dim=600, codebook_size=40, use_cosine_sim=True, **noexp)), (2, 30, 600), {}))
+    cases.append(("ResidualVQ", dict(dim=576, num_quantizers=3, cb=dict(dim=576, codebook_size=40, **noexp)), (2, 30, 576), {}))
     return cases
 
 

@@ -147,7 +147,8 @@ def test_native_modules_equal_checker_backend_at_realistic_sizes(mode, oracle):
     from vector_quantization import search
 
     failures = []
-    picked = [c for c in forward_cases() if "given_indices" not in c[3] and not c[1].get("quantize_dropout")][::5]
+    picked = [c for c in forward_cases() if "given_indices" not in c[3] and not c[1].get("quantize_dropout")
+              and c[1].get("dim") == 32][::5]  # (the dim-32 configurations are the ones _scaled knows how to enlarge)
     n_run = 0
     for i, (kind, ctor, shape, fwd) in enumerate(picked):
         ctor, shape = _scaled(ctor, shape)

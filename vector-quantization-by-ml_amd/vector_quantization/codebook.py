@@ -223,10 +223,14 @@ class Codebook(nn.Module):
             # the EMA step that follows rewrites the codebook in place; the backward pass (commitment loss: 2 (x - c))
             # must see the codes this forward used, as the reference's autograd graph does (it holds `quantize` by value)
             codes = codes.clone()
+        # (the search sweep emits the log-sum-exp only for rows one launch holds; wider rows leave it to the loss)
+        lse_here = want_lse and flat.shape[-1] <= search.LSE_MAX_DIM
         res = search.quantize_rows(flat, codes[:, None], metric=self.metric, ste=ste, want_sq_err=want_sq_err,
-                                   codebook_grad_from_err=codebook_grad_from_err, out=out, idx=idx, want_lse=want_lse,
+                                   codebook_grad_from_err=codebook_grad_from_err, out=out, idx=idx, want_lse=lse_here,
                                    packed=packed)
         out, idx, sq_err = res[:3]
+        if want_lse and not lse_here:
+            return out, idx[..., 0], sq_err, None
         if want_lse:
             best = res[3]["best"][..., 0]
             return out, idx[..., 0], sq_err, (res[3]["lse"], best if self.use_cosine_sim else -best)

@@ -445,6 +445,8 @@ def softmax_stats(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, sc
                   target: torch.Tensor | None = None, packed: torch.Tensor | None = None):
     """Per row log-sum-exp of ``scale * similarity`` over the codebook and the logit of ``target`` [H, M] int64
     (negative = ignored -> 0).  -> (lse [H, M], target_logit [H, M] | None).  [M, K] is never materialised."""
+    if x.shape[-1] > SOFTMAX_STATS_MAX_DIM:
+        return _softmax_stats_wide(x, cb, metric, scale, target, packed)
     a, packed = _aux_args(x, cb, metric, packed, 0)
     H, M = a.H, a.M
     dev = x.device
@@ -464,6 +466,30 @@ def softmax_stats(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, sc
 
 
 CE_BACKWARD_MAX_DIM = 512
+SOFTMAX_STATS_MAX_DIM = 512  # the online-softmax sweep (and the search's LSE variant) keep a row's dims in one launch
+
+
+def _softmax_stats_wide(x, cb, metric, scale, target, packed):
+    """softmax_stats for rows wider than 512 dims: the similarity matrix in bounded row chunks (the sliced MFMA sweep of
+    vq_similarities_f32), log-sum-exp and the target's logit taken from each chunk on the device."""
+    _require_gpu(x, cb)
+    H, M, _ = x.shape
+    K = cb.shape[1]
+    cb = cb.contiguous()
+    if packed is None:
+        packed = pack_codebooks(cb, metric)  # once for all row chunks
+    lse = torch.empty((H, M), dtype=torch.float32, device=x.device)
+    tl = torch.zeros((H, M), dtype=torch.float32, device=x.device) if target is not None else None
+    step = max(1, (64 << 20) // max(1, H * K))  # <= 256 MiB of matrix alive
+    for r0 in range(0, M, step):
+        logits = similarities(x[:, r0:r0 + step], cb, metric=metric, packed=packed) * scale
+        lse[:, r0:r0 + step] = torch.logsumexp(logits, dim=-1)
+        if target is not None:
+            t = target[:, r0:r0 + step]
+            picked = torch.gather(logits, 2, t.clamp(0, K - 1)[..., None])[..., 0]
+            picked = torch.where(t >= K, torch.full_like(picked, float("-inf")), picked)
+            tl[:, r0:r0 + step] = torch.where(t < 0, torch.zeros_like(picked), picked)
+    return lse, tl
 
 
 def ce_backward(x: torch.Tensor, cb: torch.Tensor, lse: torch.Tensor, target_logit: torch.Tensor, target: torch.Tensor,

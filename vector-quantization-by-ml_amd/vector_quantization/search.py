@@ -18,6 +18,9 @@ EUCLID = native.EUCLID
 DOT = native.DOT
 
 
+LSE_MAX_DIM = 512  # vq_quantize_lse_f32: rows of one launch
+
+
 def _want_deterministic(dim: int) -> bool:
     """torch.use_deterministic_algorithms(True) selects the reproducible EMA accumulation (rows of up to 2048 dims)."""
     return torch.are_deterministic_algorithms_enabled() and dim <= 2048
