@@ -85,6 +85,9 @@ def forward_cases():
                                          cb=dict(wide)), (2, 30, 640), {}))
     cases.append(("VectorQuantize", dict(dim=600, cb=dict(dim=600, codebook_size=40, use_cosine_sim=True, **noexp)), (2, 30, 600), {}))
     cases.append(("ResidualVQ", dict(dim=576, num_quantizers=3, cb=dict(dim=576, codebook_size=40, **noexp)), (2, 30, 576), {}))
+    cases.append(("VectorQuantize", dict(dim=640, cb=dict(wide)), (2, 30, 640), dict(given_indices=True)))
+    cases.append(("GroupedResidualVQ", dict(dim=1280, groups=2, num_quantizers=2, cb=dict(dim=640, codebook_size=24, **noexp)),
+                  (2, 30, 1280), {}))
     return cases
 
 
