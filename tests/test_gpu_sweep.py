@@ -150,8 +150,12 @@ def test_native_modules_equal_checker_backend_at_realistic_sizes(mode, oracle):
     picked = [c for c in forward_cases() if "given_indices" not in c[3] and not c[1].get("quantize_dropout")
               and c[1].get("dim") == 32][::5]  # (the dim-32 configurations are the ones _scaled knows how to enlarge)
     n_run = 0
-    for i, (kind, ctor, shape, fwd) in enumerate(picked):
-        ctor, shape = _scaled(ctor, shape)
+    sized = [(kind, *_scaled(ctor, shape), fwd) for kind, ctor, shape, fwd in picked]
+    # rows wider than 512 dims at realistic sizes (sliced sweep: several slices, K % 32 != 0, EMA over wide rows)
+    noexp = dict(threshold_ema_dead_code=0)
+    sized.append(("VectorQuantize", dict(dim=768, cb=dict(dim=768, codebook_size=1000, **noexp)), (8, 512, 768), {}))
+    sized.append(("ResidualVQ", dict(dim=640, num_quantizers=3, cb=dict(dim=640, codebook_size=500, **noexp)), (4, 256, 640), {}))
+    for i, (kind, ctor, shape, fwd) in enumerate(sized):
         cpu_mod, ctor_kw, cb_kw = _build(kind, ctor)
         if getattr(cpu_mod, "has_projections", False):
             continue  # nn.Linear in front: MKL vs rocBLAS rounding moves near-ties at these sizes (not this library's kernels)
