@@ -103,7 +103,7 @@ int allow_big_lds(K kern, bool (&done)[kMaxDevices]) {
 template <int DP, int WAVES, int METRIC, int MULTI, bool LSE = false, int XT = 0, int WIDE = 0>
 int launch_search_t(const SearchParams &p, int H, int splits, hipStream_t s) {
     using G = Geo<DP, WAVES>;
-    const size_t lds = (size_t)(MULTI ? G::MAIN_FLOATS_M : G::MAIN_FLOATS) * 4 + (size_t)WAVES * p.Q * 32 * 4 +
+    const size_t lds = (size_t)(MULTI ? G::MAIN_FLOATS_M : G::MAIN_FLOATS_S) * 4 + (size_t)WAVES * p.Q * 32 * 4 +
                        ((MULTI && p.loss_part) ? (size_t)WAVES * p.Q * 64 * 4 : 0);
     if (lds > 160 * 1024) return fail(VQ_E_UNSUPPORTED, "vq_search: LDS budget exceeded (too many residual stages)");
     auto kern = vq_search_mfma<DP, WAVES, METRIC, MULTI, LSE, XT, WIDE>;
@@ -203,7 +203,7 @@ bool persist_selected(int DP, int waves, const SearchParams &p, int H, int split
 template <int METRIC>
 int launch_persist_t(const SearchParams &p, int H, int cus, hipStream_t s) {
     using G = Geo<256, 8>;
-    const size_t lds = (size_t)G::MAIN_FLOATS * 4 + 2 * 8 * 32 * 4;
+    const size_t lds = (size_t)G::MAIN_FLOATS_S * 4 + 2 * 8 * 32 * 4;
     auto kern = vq_search_persist<256, 8, METRIC>;
     static thread_local bool attr_done[kMaxDevices] = {};
     if (int rc = allow_big_lds(kern, attr_done)) return rc;
@@ -523,7 +523,38 @@ int run_wide(const vq_args *a, long long idx_offset, long long *keys, float *sim
     return 0;
 }
 
-int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hipStream_t s) {
+// Rows per workgroup of the fused single-stage launch at Dp >= 256 (one workgroup per CU): 256 (8 waves x 32) at Dp = 256,
+// 128 (4 wave pairs / 4 waves) at Dp = 512.
+inline int fused_rows_per_wg(int DP) { return DP == 512 ? 128 : 256; }
+
+// Quantisation of the grid: with one workgroup per CU the launch runs in rounds of `cus` workgroups, and a row count just
+// above a multiple of cus x rows-per-workgroup pays a whole extra round (M = 70 000 at D = 256: 274 workgroups = 2 rounds for
+// 1.07 rounds of work).  Splitting K over S workgroups per row block makes the rounds shorter and fuller at the price of one
+// more prologue per split and the keys + finalize tail.  Costs in units of one sub-tile of sweep (8 waves): prologue ~1.5,
+// fused finalize ~1.2, keys-init + finalize kernels ~ 3 + rows x D x 8 bytes at ~5 TB/s.  Returns the best S (1 = stay fused).
+int plan_k_split(int DP, int H, long long M, int K, int D, int cus) {
+    const int rpw = fused_rows_per_wg(DP);
+    const long long nblk = (M + rpw - 1) / rpw * H;
+    const int nsub = (K + kTileCodes - 1) / kTileCodes;
+    if (nblk * 2 <= cus || nsub < 16) return 1;  // (few workgroups: the older rule below splits until the chip is full)
+    const double sub_us = (DP == 512 ? 14.4 : 7.2);  // one sub-tile of all the workgroup's waves, microseconds
+    const double tail = 3.0 + (double)M * H * D * 8.0 / 5e6 / sub_us;  // keys init + finalize kernels
+    auto rounds = [&](long long wgs) { return (double)((wgs + cus - 1) / cus); };
+    const double fused = rounds(nblk) * (1.5 + nsub + 1.2);
+    double best = fused;
+    int best_s = 1;
+    for (int S = 2; S <= 16 && S * 8 <= nsub; ++S) {
+        const int per = (nsub + S - 1) / S;
+        const double t = rounds(nblk * S) * (1.5 + per) + tail;
+        if (t < best) {
+            best = t;
+            best_s = S;
+        }
+    }
+    return best < 0.88 * fused ? best_s : 1;
+}
+
+int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hipStream_t s, int planned_splits = 0) {
     const int DP = padded_dim(a->D);
     if (DP == 0 && !(a->flags & VQ_F_FORCE_SIMPLE)) return run_wide(a, idx_offset, keys, nullptr, 0, 0, s);
     const bool simple = (a->flags & VQ_F_FORCE_SIMPLE) || DP == 0;
@@ -555,7 +586,7 @@ int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hip
     const int cus = di.ok && di.cus > 0 ? di.cus : 256;
     int waves = (DP == 512) ? 4 : 8;
     long long wgs = (long long)a->H * ((a->M + 32 * waves - 1) / (32 * waves));
-    if (waves == 8 && wgs < cus) {
+    if (waves == 8 && wgs < cus && planned_splits == 0) {
         waves = 4;
         wgs = (long long)a->H * ((a->M + 127) / 128);
     }
@@ -563,7 +594,9 @@ int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hip
     // further only repeats the prologue and, in the wave-pair kernel, the extra pipeline step
     const long long fill = (long long)cus * (DP == 512 ? 1 : 2);
     int splits = 1;
-    if (wgs < fill) {
+    if (planned_splits > 0) {
+        splits = planned_splits < p.ntiles ? planned_splits : p.ntiles;  // (plan_k_split: full-size workgroups, S splits)
+    } else if (wgs < fill) {
         splits = (int)((fill + wgs - 1) / wgs);
         if (splits > p.ntiles) splits = p.ntiles;
         if (splits < 1) splits = 1;
@@ -719,6 +752,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
 
     // ---- choose fused (one launch, no K split) or split (keys + finalize) ----
     bool fused = !simple;
+    int planned_splits = 0;
     int waves = (DP == 512) ? 4 : 8;
     if (fused) {
         long long wgs = (long long)a->H * ((a->M + 32 * waves - 1) / (32 * waves));
@@ -733,6 +767,10 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         // few workgroups and a long sweep: splitting K over workgroups fills the chip (Q == 1 only)
         if (a->Q == 1 && wgs * 2 <= cus && ntiles * sub_tiles(DP) >= 8 && ntiles >= 2) fused = false;
         if ((a->flags & VQ_F_FORCE_SPLIT) && a->Q == 1) fused = false;
+        if (fused && a->Q == 1 && DP >= 256 && !(a->flags & (VQ_F_X_F16 | VQ_F_X_BF16))) {
+            planned_splits = plan_k_split(DP, a->H, a->M, a->K, a->D, cus);  // grid quantisation (see plan_k_split)
+            if (planned_splits > 1) fused = false;
+        }
         if (lse) fused = true;  // the log-sum-exp needs every code of a row in one workgroup
         if ((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err) fused = true;  // per-head partial sums exist on this path only
     }
@@ -767,7 +805,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         return fail(VQ_E_UNSUPPORTED, "vq_quantize: per-head squared errors need the MFMA kernel (D <= 512)");
     rc = vq_keys_init((int64_t *)keys, (int64_t)a->H * a->M, stream);
     if (rc) return rc;
-    rc = run_search_keys(a, 0, keys, s);
+    rc = run_search_keys(a, 0, keys, s, fused ? 0 : planned_splits);
     if (rc) return rc;
     int nparts = 0;
     rc = run_finalize(a, keys, a->sq_err ? loss_part : nullptr, s, &nparts);
