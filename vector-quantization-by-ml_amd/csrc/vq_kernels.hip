@@ -523,8 +523,9 @@ int run_wide(const vq_args *a, long long idx_offset, long long *keys, float *sim
     return 0;
 }
 
-// Rows per workgroup of the fused single-stage launch at Dp >= 256 (one workgroup per CU): 256 (8 waves x 32) at Dp = 256,
-// 128 (4 wave pairs / 4 waves) at Dp = 512.
+// Rows per workgroup of the fused single-stage launch: 256 (8 waves x 32), 128 (4 wave pairs / 4 waves) at Dp = 512.
+// (At Dp <= 128 two 8-wave workgroups share a CU, but a lone one already runs at ~0.93 of the CU's MFMA rate, so a CU is
+//  still one slot of the rounds model below, to within a few percent.)
 inline int fused_rows_per_wg(int DP) { return DP == 512 ? 128 : 256; }
 
 // Quantisation of the grid: with one workgroup per CU the launch runs in rounds of `cus` workgroups, and a row count just
@@ -537,7 +538,7 @@ int plan_k_split(int DP, int H, long long M, int K, int D, int cus) {
     const long long nblk = (M + rpw - 1) / rpw * H;
     const int nsub = (K + kTileCodes - 1) / kTileCodes;
     if (nblk * 2 <= cus || nsub < 16) return 1;  // (few workgroups: the older rule below splits until the chip is full)
-    const double sub_us = (DP == 512 ? 14.4 : 7.2);  // one sub-tile of all the workgroup's waves, microseconds
+    const double sub_us = 7.2 * DP / 256.0;  // one sub-tile of all the workgroup's waves, microseconds (measured at Dp = 256)
     const double tail = 3.0 + (double)M * H * D * 8.0 / 5e6 / sub_us;  // keys init + finalize kernels
     auto rounds = [&](long long wgs) { return (double)((wgs + cus - 1) / cus); };
     const double fused = rounds(nblk) * (1.5 + nsub + 1.2);
@@ -767,7 +768,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         // few workgroups and a long sweep: splitting K over workgroups fills the chip (Q == 1 only)
         if (a->Q == 1 && wgs * 2 <= cus && ntiles * sub_tiles(DP) >= 8 && ntiles >= 2) fused = false;
         if ((a->flags & VQ_F_FORCE_SPLIT) && a->Q == 1) fused = false;
-        if (fused && a->Q == 1 && DP >= 256 && !(a->flags & (VQ_F_X_F16 | VQ_F_X_BF16))) {
+        if (fused && a->Q == 1 && !(a->flags & (VQ_F_X_F16 | VQ_F_X_BF16))) {
             planned_splits = plan_k_split(DP, a->H, a->M, a->K, a->D, cus);  // grid quantisation (see plan_k_split)
             if (planned_splits > 1) fused = false;
         }
