@@ -354,6 +354,38 @@ int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipS
     return 0;
 }
 
+// Rows per workgroup of the fused single-stage launch: 256 (8 waves x 32), 128 (4 wave pairs / 4 waves) at Dp = 512.
+// (At Dp <= 128 two 8-wave workgroups share a CU, but a lone one already runs at ~0.93 of the CU's MFMA rate, so a CU is
+//  still one slot of the rounds model below, to within a few percent.)
+inline int fused_rows_per_wg(int DP) { return DP == 512 ? 128 : 256; }
+
+// Quantisation of the grid: with one workgroup per CU the launch runs in rounds of `cus` workgroups, and a row count just
+// above a multiple of cus x rows-per-workgroup pays a whole extra round (M = 70 000 at D = 256: 274 workgroups = 2 rounds for
+// 1.07 rounds of work).  Splitting K over S workgroups per row block makes the rounds shorter and fuller at the price of one
+// more prologue per split and the keys + finalize tail.  Costs in units of one sub-tile of sweep (8 waves): prologue ~1.5,
+// fused finalize ~1.2, keys-init + finalize kernels ~ 3 + rows x D x 8 bytes at ~5 TB/s.  Returns the best S (1 = stay fused).
+int plan_k_split(int DP, int H, long long M, int K, int D, int cus) {
+    const int rpw = fused_rows_per_wg(DP);
+    const long long nblk = (M + rpw - 1) / rpw * H;
+    const int nsub = (K + kTileCodes - 1) / kTileCodes;
+    if (nblk * 2 <= cus || nsub < 16) return 1;  // (few workgroups: the older rule below splits until the chip is full)
+    const double sub_us = 7.2 * DP / 256.0;  // one sub-tile of all the workgroup's waves, microseconds (measured at Dp = 256)
+    const double tail = 3.0 + (double)M * H * D * 8.0 / 5e6 / sub_us;  // keys init + finalize kernels
+    auto rounds = [&](long long wgs) { return (double)((wgs + cus - 1) / cus); };
+    const double fused = rounds(nblk) * (1.5 + nsub + 1.2);
+    double best = fused;
+    int best_s = 1;
+    for (int S = 2; S <= 16 && S * 8 <= nsub; ++S) {
+        const int per = (nsub + S - 1) / S;
+        const double t = rounds(nblk * S) * (1.5 + per) + tail;
+        if (t < best) {
+            best = t;
+            best_s = S;
+        }
+    }
+    return best < 0.88 * fused ? best_s : 1;
+}
+
 // ---- rows wider than 512 dims -------------------------------------------------------------------
 // The distance of a (row, code) pair is ONE k-ordered fmaf chain over all dims, so the sweep is cut along d into slices of
 // kWideSlice dims: slice j continues the chains slice j - 1 left in the workspace (the accumulators' own fragment layout: every
@@ -437,7 +469,9 @@ bool wide_fusable(const vq_args *a) {
     const int cus = di.ok && di.cus > 0 ? di.cus : 256;
     const WidePlan w = wide_plan(a->H, a->M, a->K, a->D);
     const long long last_rows = a->M % w.mc ? a->M % w.mc : w.mc;  // the smallest row chunk
-    return ((last_rows + kWideRows - 1) / kWideRows) * a->H >= cus;
+    if (((last_rows + kWideRows - 1) / kWideRows) * a->H < cus) return false;
+    // a row count that leaves the last round of workgroups mostly empty is better served by a K split (keys path)
+    return plan_k_split(kWideSlice, a->H, w.mc < a->M ? w.mc : a->M, a->K, kWideSlice, cus) == 1;
 }
 
 // `keys` (search: argmin into packed keys), `sims` (the similarity matrix itself) or `fused` (the whole inference call)
@@ -484,6 +518,9 @@ int run_wide(const vq_args *a, long long idx_offset, long long *keys, float *sim
                 if (nblk * a->H < fill) {
                     splits = (int)((fill + nblk * a->H - 1) / (nblk * a->H));
                     if (splits > p.ntiles) splits = p.ntiles;
+                } else if (!fused) {
+                    splits = plan_k_split(DP, a->H, mrows, kcodes, DP, cus);  // partly filled last round of workgroups
+                    if (splits > p.ntiles) splits = p.ntiles;
                 }
                 p.tiles_per_split = (p.ntiles + splits - 1) / splits;
                 splits = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
@@ -521,38 +558,6 @@ int run_wide(const vq_args *a, long long idx_offset, long long *keys, float *sim
         }
     }
     return 0;
-}
-
-// Rows per workgroup of the fused single-stage launch: 256 (8 waves x 32), 128 (4 wave pairs / 4 waves) at Dp = 512.
-// (At Dp <= 128 two 8-wave workgroups share a CU, but a lone one already runs at ~0.93 of the CU's MFMA rate, so a CU is
-//  still one slot of the rounds model below, to within a few percent.)
-inline int fused_rows_per_wg(int DP) { return DP == 512 ? 128 : 256; }
-
-// Quantisation of the grid: with one workgroup per CU the launch runs in rounds of `cus` workgroups, and a row count just
-// above a multiple of cus x rows-per-workgroup pays a whole extra round (M = 70 000 at D = 256: 274 workgroups = 2 rounds for
-// 1.07 rounds of work).  Splitting K over S workgroups per row block makes the rounds shorter and fuller at the price of one
-// more prologue per split and the keys + finalize tail.  Costs in units of one sub-tile of sweep (8 waves): prologue ~1.5,
-// fused finalize ~1.2, keys-init + finalize kernels ~ 3 + rows x D x 8 bytes at ~5 TB/s.  Returns the best S (1 = stay fused).
-int plan_k_split(int DP, int H, long long M, int K, int D, int cus) {
-    const int rpw = fused_rows_per_wg(DP);
-    const long long nblk = (M + rpw - 1) / rpw * H;
-    const int nsub = (K + kTileCodes - 1) / kTileCodes;
-    if (nblk * 2 <= cus || nsub < 16) return 1;  // (few workgroups: the older rule below splits until the chip is full)
-    const double sub_us = 7.2 * DP / 256.0;  // one sub-tile of all the workgroup's waves, microseconds (measured at Dp = 256)
-    const double tail = 3.0 + (double)M * H * D * 8.0 / 5e6 / sub_us;  // keys init + finalize kernels
-    auto rounds = [&](long long wgs) { return (double)((wgs + cus - 1) / cus); };
-    const double fused = rounds(nblk) * (1.5 + nsub + 1.2);
-    double best = fused;
-    int best_s = 1;
-    for (int S = 2; S <= 16 && S * 8 <= nsub; ++S) {
-        const int per = (nsub + S - 1) / S;
-        const double t = rounds(nblk * S) * (1.5 + per) + tail;
-        if (t < best) {
-            best = t;
-            best_s = S;
-        }
-    }
-    return best < 0.88 * fused ? best_s : 1;
 }
 
 int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hipStream_t s, int planned_splits = 0) {
