@@ -364,10 +364,11 @@ inline int fused_rows_per_wg(int DP) { return DP == 512 ? 128 : 256; }
 // 1.07 rounds of work).  Splitting K over S workgroups per row block makes the rounds shorter and fuller at the price of one
 // more prologue per split and the keys + finalize tail.  Costs in units of one sub-tile of sweep (8 waves): prologue ~1.5,
 // fused finalize ~1.2, keys-init + finalize kernels ~ 3 + rows x D x 8 bytes at ~5 TB/s.  Returns the best S (1 = stay fused).
-int plan_k_split(int DP, int H, long long M, int K, int D, int cus) {
+int plan_k_split(int DP, int H, long long M, int K, int D, int cus, double *cost = nullptr, double *fused_cost = nullptr) {
     const int rpw = fused_rows_per_wg(DP);
     const long long nblk = (M + rpw - 1) / rpw * H;
     const int nsub = (K + kTileCodes - 1) / kTileCodes;
+    if (cost) *cost = *fused_cost = (double)((nblk + cus - 1) / cus) * (1.5 + nsub + 1.2);
     if (nblk * 2 <= cus || nsub < 16) return 1;  // (few workgroups: the older rule below splits until the chip is full)
     const double sub_us = 7.2 * DP / 256.0;  // one sub-tile of all the workgroup's waves, microseconds (measured at Dp = 256)
     const double tail = 3.0 + (double)M * H * D * 8.0 / 5e6 / sub_us;  // keys init + finalize kernels
@@ -383,7 +384,31 @@ int plan_k_split(int DP, int H, long long M, int K, int D, int cus) {
             best_s = S;
         }
     }
-    return best < 0.88 * fused ? best_s : 1;
+    if (best >= 0.88 * fused) return 1;
+    if (cost) *cost = best;
+    return best_s;
+}
+
+// Third remedy for the same quantisation, single head, inference call: the row blocks that fill whole rounds run fused, the
+// remainder (fewer blocks than CUs) is searched by a second call, which splits K until the chip is full -- a short round
+// instead of a whole one.  Returns the rows of the fused part, 0 when the model does not predict >= 5 % over both alternatives.
+long long plan_main_tail(int DP, long long M, int K, int D, int cus) {
+    const int rpw = fused_rows_per_wg(DP);
+    const long long nblk = (M + rpw - 1) / rpw;
+    const long long full = nblk / cus, rem = nblk % cus;
+    const int nsub = (K + kTileCodes - 1) / kTileCodes;
+    if (full < 1 || rem == 0 || nsub < 8) return 0;
+    double plan_cost = 0.0, fused_cost = 0.0;
+    plan_k_split(DP, 1, M, K, D, cus, &plan_cost, &fused_cost);
+    int st = (int)((cus + rem - 1) / rem);
+    if (st > nsub / 8) st = nsub / 8;
+    if (st < 1) st = 1;
+    const int per = (nsub + st - 1) / st;
+    const double sub_us = 7.2 * DP / 256.0;
+    const double tail = (double)((rem * st + cus - 1) / cus) * (1.5 + per) + 3.0 + (double)(rem * rpw) * D * 8.0 / 5e6 / sub_us;
+    const double hybrid = (double)full * (1.5 + nsub + 1.2) + tail;
+    const double other = plan_cost < fused_cost ? plan_cost : fused_cost;
+    return hybrid < 0.95 * other ? full * cus * rpw : 0;
 }
 
 // ---- rows wider than 512 dims -------------------------------------------------------------------
@@ -755,6 +780,23 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     const bool simple = (a->flags & VQ_F_FORCE_SIMPLE) || DP == 0;
     const DevInfo &di = dev_info();
     const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+
+    if (!simple && a->H == 1 && a->Q == 1 && !lse && !a->sq_err &&
+        !(a->flags & (VQ_F_FORCE_SPLIT | VQ_F_X_F16 | VQ_F_X_BF16))) {
+        const long long m1 = plan_main_tail(DP, a->M, a->K, a->D, cus);
+        if (m1 > 0 && m1 < a->M) {  // whole rounds fused, then the remainder as its own (K-split) call
+            vq_args a1 = *a, a2 = *a;
+            a1.M = m1;
+            a2.M = a->M - m1;
+            a2.x = a->x + m1 * a->x_rs;
+            if (a->out) a2.out = a->out + m1 * a->out_rs;
+            a2.idx = a->idx + m1 * a->idx_rs;
+            if (a->best) a2.best = a->best + m1 * a->idx_rs;
+            rc = quantize_impl(&a1, stream, nullptr);
+            if (rc) return rc;
+            return quantize_impl(&a2, stream, nullptr);
+        }
+    }
 
     // ---- choose fused (one launch, no K split) or split (keys + finalize) ----
     bool fused = !simple;
