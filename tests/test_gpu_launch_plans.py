@@ -1,0 +1,43 @@
+"""GPU: the launch plans for row counts that do not fill whole rounds of workgroups (csrc/vq_kernels.hip plan_k_split /
+plan_main_tail): K split over several workgroups per row block, or whole rounds fused + the remainder as its own K-split call.
+Results must not depend on the plan: indices, winning distances and outputs equal the one-thread-per-row kernel on every row,
+the squared-error sum (one sum over both parts of a two-call plan) agrees to 1e-6, eval and training outputs alike."""
+from __future__ import annotations
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+CASES = [
+    # (M, K, D, metric)          what the planner does with it on a 256-CU device
+    (70000, 1024, 256, 0),      # 274 row blocks: 256 fused + 18 as a K-split tail
+    (131073, 1024, 256, 0),     # 513 row blocks, the last one holds ONE row
+    (66000, 8192, 256, 0),      # 258 row blocks, long sweep
+    (40000, 4096, 256, 1),      # 157 row blocks (< one round): K split 3 ways
+    (40000, 4096, 512, 0),      # wave-pair kernel in keys mode
+    (70000, 8192, 64, 0),       # Dp = 64
+    (200000, 1024, 64, 1),
+    (150000, 4096, 128, 0),
+]
+
+
+@pytest.mark.parametrize("M,K,D,metric", CASES)
+@pytest.mark.parametrize("training", [False, True])
+def test_planned_launches_equal_scalar_kernel(M, K, D, metric, training):
+    from vector_quantization import native
+
+    native.load()
+    g = torch.Generator(device=DEV).manual_seed(M + K + D)
+    x = torch.randn((1, M, D), device=DEV, generator=g)
+    cb = torch.randn((1, 1, K, D), device=DEV, generator=g)
+    r = native.quantize(x, cb, metric=metric, ste=training, want_sq_err=training)
+    s = native.quantize(x, cb, metric=metric, ste=training, want_sq_err=training, flags=native.F_FORCE_SIMPLE)
+    torch.cuda.synchronize()
+    assert torch.equal(r["idx"], s["idx"])
+    assert torch.equal(r["best"].view(torch.int32), s["best"].view(torch.int32))
+    assert torch.equal(r["out"], s["out"])
+    if training:
+        torch.testing.assert_close(r["sq_err"], s["sq_err"], rtol=1e-6, atol=0)

@@ -756,6 +756,8 @@ int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream) {
     return 0;
 }
 
+constexpr uint32_t kFlagAccumulateSqErr = 0x80000000u;  // never set by callers: vq_quantize_f32 masks it off
+
 static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     int rc = check_common(a);
     if (rc) return rc;
@@ -781,7 +783,8 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     const DevInfo &di = dev_info();
     const int cus = di.ok && di.cus > 0 ? di.cus : 256;
 
-    if (!simple && a->H == 1 && a->Q == 1 && !lse && !a->sq_err &&
+    const int acc = (a->flags & kFlagAccumulateSqErr) ? 1 : 0;  // (internal: second call of a two-call plan adds its sum)
+    if (!simple && a->H == 1 && a->Q == 1 && !lse && !acc &&
         !(a->flags & (VQ_F_FORCE_SPLIT | VQ_F_X_F16 | VQ_F_X_BF16))) {
         const long long m1 = plan_main_tail(DP, a->M, a->K, a->D, cus);
         if (m1 > 0 && m1 < a->M) {  // whole rounds fused, then the remainder as its own (K-split) call
@@ -792,6 +795,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
             if (a->out) a2.out = a->out + m1 * a->out_rs;
             a2.idx = a->idx + m1 * a->idx_rs;
             if (a->best) a2.best = a->best + m1 * a->idx_rs;
+            if (a->sq_err) a2.flags |= kFlagAccumulateSqErr;  // one squared-error sum over both parts, fixed order
             rc = quantize_impl(&a1, stream, nullptr);
             if (rc) return rc;
             return quantize_impl(&a2, stream, nullptr);
@@ -840,7 +844,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
             const long long per_head = ((a->M + rows_per_wg - 1) / rows_per_wg) * (pair ? 8 : waves);
             const bool by_head = (a->flags & VQ_F_SQERR_PER_HEAD) != 0;
             hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(a->Q, by_head ? a->H : 1), dim3(256), 0, s, loss_part,
-                               by_head ? per_head : per_head * a->H, a->Q, a->sq_err);
+                               by_head ? per_head : per_head * a->H, a->Q, a->sq_err, acc);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
         }
@@ -859,17 +863,29 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     rc = run_finalize(a, keys, a->sq_err ? loss_part : nullptr, s, &nparts);
     if (rc) return rc;
     if (a->sq_err) {
-        hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_part, (long long)nparts, 1, a->sq_err);
+        hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_part, (long long)nparts, 1, a->sq_err, acc);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
     }
     return 0;
 }
 
-int vq_quantize_f32(const vq_args *a, void *stream) { return quantize_impl(a, stream, nullptr); }
+int vq_quantize_f32(const vq_args *a, void *stream) {
+    if (a && (a->flags & kFlagAccumulateSqErr)) {
+        vq_args b = *a;
+        b.flags &= ~kFlagAccumulateSqErr;
+        return quantize_impl(&b, stream, nullptr);
+    }
+    return quantize_impl(a, stream, nullptr);
+}
 
 int vq_quantize_lse_f32(const vq_args *a, float *lse, void *stream) {
     if (!lse && a && a->M > 0) return fail(VQ_E_BADARG, "vq_quantize_lse: lse is null");
+    if (a && (a->flags & kFlagAccumulateSqErr)) {
+        vq_args b = *a;
+        b.flags &= ~kFlagAccumulateSqErr;
+        return quantize_impl(&b, stream, lse);
+    }
     return quantize_impl(a, stream, lse);
 }
 
