@@ -41,3 +41,24 @@ def test_planned_launches_equal_scalar_kernel(M, K, D, metric, training):
     assert torch.equal(r["out"], s["out"])
     if training:
         torch.testing.assert_close(r["sq_err"], s["sq_err"], rtol=1e-6, atol=0)
+
+
+def test_module_forward_with_planned_launches_matches_scalar_search():
+    """The modules hand strided views (channel-first input, [rows, heads]-ordered index buffers) to the planned launches."""
+    import vector_quantization as vq
+    from vector_quantization import native
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(0)
+    for channel_last in (True, False):
+        mod = vq.VectorQuantize(dim=256, channel_last=channel_last,
+                                codebook_params=CodebookParams(dim=256, codebook_size=1024)).to(DEV).eval()
+        x = torch.randn(70, 1000, 256, device=DEV)  # 70 000 rows: whole rounds fused + a K-split tail
+        xin = x if channel_last else x.permute(0, 2, 1).contiguous()
+        with torch.no_grad():
+            q, idx, _ = mod(xin)
+        flat = x.reshape(1, -1, 256)
+        ref = native.quantize(flat, mod._codebook.embeddings.detach()[:, None].contiguous(), flags=native.F_FORCE_SIMPLE)
+        assert torch.equal(idx.reshape(-1), ref["idx"].reshape(-1))
+        qq = q if channel_last else q.permute(0, 2, 1)
+        assert torch.equal(qq.reshape(-1, 256), ref["out"].reshape(-1, 256))
