@@ -12,27 +12,30 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 CASES = [
-    # (M, K, D, metric)          what the planner does with it on a 256-CU device
-    (70000, 1024, 256, 0),      # 274 row blocks: 256 fused + 18 as a K-split tail
-    (131073, 1024, 256, 0),     # 513 row blocks, the last one holds ONE row
-    (66000, 8192, 256, 0),      # 258 row blocks, long sweep
-    (40000, 4096, 256, 1),      # 157 row blocks (< one round): K split 3 ways
-    (40000, 4096, 512, 0),      # wave-pair kernel in keys mode
-    (70000, 8192, 64, 0),       # Dp = 64
-    (200000, 1024, 64, 1),
-    (150000, 4096, 128, 0),
+    # (H, M, K, D, metric)          what the planner does with it on a 256-CU device
+    (1, 70000, 1024, 256, 0),      # 274 row blocks: 256 fused + 18 as a K-split tail
+    (1, 131073, 1024, 256, 0),     # 513 row blocks, the last one holds ONE row
+    (1, 66000, 8192, 256, 0),      # 258 row blocks, long sweep
+    (1, 40000, 4096, 256, 1),      # 157 row blocks (< one round): K split 3 ways
+    (1, 40000, 4096, 512, 0),      # wave-pair kernel in keys mode
+    (1, 70000, 8192, 64, 0),       # Dp = 64
+    (1, 200000, 1024, 64, 1),
+    (1, 150000, 4096, 128, 0),
+    (8, 10000, 8192, 64, 0),       # several heads: 320 workgroups = 256 fused (32 row blocks of every head) + a tail
+    (4, 20000, 2048, 256, 1),
+    (6, 9000, 1024, 512, 0),       # heads that do not divide the CU count
 ]
 
 
-@pytest.mark.parametrize("M,K,D,metric", CASES)
+@pytest.mark.parametrize("H,M,K,D,metric", CASES)
 @pytest.mark.parametrize("training", [False, True])
-def test_planned_launches_equal_scalar_kernel(M, K, D, metric, training):
+def test_planned_launches_equal_scalar_kernel(H, M, K, D, metric, training):
     from vector_quantization import native
 
     native.load()
     g = torch.Generator(device=DEV).manual_seed(M + K + D)
-    x = torch.randn((1, M, D), device=DEV, generator=g)
-    cb = torch.randn((1, 1, K, D), device=DEV, generator=g)
+    x = torch.randn((H, M, D), device=DEV, generator=g)
+    cb = torch.randn((H, 1, K, D), device=DEV, generator=g)
     r = native.quantize(x, cb, metric=metric, ste=training, want_sq_err=training)
     s = native.quantize(x, cb, metric=metric, ste=training, want_sq_err=training, flags=native.F_FORCE_SIMPLE)
     torch.cuda.synchronize()

@@ -389,26 +389,29 @@ int plan_k_split(int DP, int H, long long M, int K, int D, int cus, double *cost
     return best_s;
 }
 
-// Third remedy for the same quantisation, single head, inference call: the row blocks that fill whole rounds run fused, the
+// Third remedy for the same quantisation: the row blocks that fill whole rounds run fused, the
 // remainder (fewer blocks than CUs) is searched by a second call, which splits K until the chip is full -- a short round
 // instead of a whole one.  Returns the rows of the fused part, 0 when the model does not predict >= 5 % over both alternatives.
-long long plan_main_tail(int DP, long long M, int K, int D, int cus) {
+long long plan_main_tail(int DP, int H, long long M, int K, int D, int cus) {
     const int rpw = fused_rows_per_wg(DP);
-    const long long nblk = (M + rpw - 1) / rpw;
-    const long long full = nblk / cus, rem = nblk % cus;
+    const long long nblk_h = (M + rpw - 1) / rpw;  // row blocks per head; every head gets the same cut
+    long long full = nblk_h * H / cus;
+    while (full > 0 && (full * cus) % H) --full;   // whole rounds that are also whole row blocks of every head
+    const long long rem = nblk_h * H - full * cus;
     const int nsub = (K + kTileCodes - 1) / kTileCodes;
-    if (full < 1 || rem == 0 || nsub < 8) return 0;
+    if (full < 1 || rem == 0 || rem >= cus || nsub < 8) return 0;
     double plan_cost = 0.0, fused_cost = 0.0;
-    plan_k_split(DP, 1, M, K, D, cus, &plan_cost, &fused_cost);
+    plan_k_split(DP, H, M, K, D, cus, &plan_cost, &fused_cost);
     int st = (int)((cus + rem - 1) / rem);
     if (st > nsub / 8) st = nsub / 8;
     if (st < 1) st = 1;
     const int per = (nsub + st - 1) / st;
     const double sub_us = 7.2 * DP / 256.0;
     const double tail = (double)((rem * st + cus - 1) / cus) * (1.5 + per) + 3.0 + (double)(rem * rpw) * D * 8.0 / 5e6 / sub_us;
+    // (rem counts workgroups of all heads together)
     const double hybrid = (double)full * (1.5 + nsub + 1.2) + tail;
     const double other = plan_cost < fused_cost ? plan_cost : fused_cost;
-    return hybrid < 0.95 * other ? full * cus * rpw : 0;
+    return hybrid < 0.95 * other ? full * cus / H * rpw : 0;
 }
 
 // ---- rows wider than 512 dims -------------------------------------------------------------------
@@ -784,9 +787,9 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     const int cus = di.ok && di.cus > 0 ? di.cus : 256;
 
     const int acc = (a->flags & kFlagAccumulateSqErr) ? 1 : 0;  // (internal: second call of a two-call plan adds its sum)
-    if (!simple && a->H == 1 && a->Q == 1 && !lse && !acc &&
+    if (!simple && a->Q == 1 && !lse && !acc && !((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err) &&
         !(a->flags & (VQ_F_FORCE_SPLIT | VQ_F_X_F16 | VQ_F_X_BF16))) {
-        const long long m1 = plan_main_tail(DP, a->M, a->K, a->D, cus);
+        const long long m1 = plan_main_tail(DP, a->H, a->M, a->K, a->D, cus);
         if (m1 > 0 && m1 < a->M) {  // whole rounds fused, then the remainder as its own (K-split) call
             vq_args a1 = *a, a2 = *a;
             a1.M = m1;
