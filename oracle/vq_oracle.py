@@ -143,18 +143,23 @@ def rvq_forward(x: np.ndarray, cbs: np.ndarray, metric: int = EUCLID, training: 
 def pack_key(best: np.ndarray, idx: np.ndarray, metric: int = EUCLID) -> np.ndarray:
     """(value, index) -> one SIGNED int64 whose MIN picks the winner with lowest-index ties.
 
-    hi word: m = "smaller is better" unsigned image of the value (Euclid: the IEEE bits of the
-    non-negative sqrt distance; dot: complement of the usual order-preserving float->uint map),
-    stored with its top bit flipped so that signed comparison == unsigned comparison of m.
+    hi word: m = "smaller is better" unsigned image of the value, stored with its top bit flipped so that signed
+    comparison == unsigned comparison of m.  Euclid: 1 + the IEEE bits of the non-negative sqrt distance, and 0 for a
+    NaN (argmax treats a NaN similarity as the maximum, utils/general.py:128: it must beat distance 0); dot: complement
+    of the usual order-preserving float->uint map, NaN canonicalised to the positive quiet NaN (which that map already
+    places above +inf).
     lo word: the code index.
     """
-    bits = np.ascontiguousarray(best, dtype=np.float32).view(np.uint32)
+    best = np.ascontiguousarray(best, dtype=np.float32)
+    nan = np.isnan(best)
+    bits = best.view(np.uint32)
     if metric == DOT:
+        bits = np.where(nan, np.uint32(0x7FC00000), bits).astype(np.uint32)
         neg = (bits >> np.uint32(31)) != 0
         mono = np.where(neg, ~bits, bits | np.uint32(0x80000000)).astype(np.uint32)
         m = ~mono
     else:
-        m = bits
+        m = np.where(nan, np.uint32(0), bits + np.uint32(1)).astype(np.uint32)
     hi = (m ^ np.uint32(0x80000000)).view(np.int32).astype(np.int64)
     return (hi << np.int64(32)) | idx.astype(np.int64)
 
@@ -169,5 +174,5 @@ def unpack_key(key: np.ndarray, metric: int = EUCLID):
         pos = (mono >> np.uint32(31)) != 0
         bits = np.where(pos, mono ^ np.uint32(0x80000000), ~mono).astype(np.uint32)
     else:
-        bits = m
+        bits = np.where(m == 0, np.uint32(0x7FC00000), m - np.uint32(1)).astype(np.uint32)
     return bits.view(np.float32), idx

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from gen import CB_SEED, l2norm, make_codebook, make_rvq_codebooks, make_x, seeded_projection_
+from gen import CB_SEED, l2norm, make_codebook, make_rvq_codebooks, make_x, poison_, seeded_projection_
 
 
 def make_mask(b, n):
@@ -60,6 +60,7 @@ def build(case, arrays=None, device="cpu"):
         cb = make_codebook(h, K, d, case["cls"])
         if case.get("weights_regularization", "identity") == "l2norm":
             cb = l2norm(cb)
+        poison_(x, cb, case.get("nonfinite"))
         with torch.no_grad():
             mod._codebook.embeddings.copy_(cb)
             mod._codebook.embed_avg.copy_(cb)
@@ -84,6 +85,7 @@ def build(case, arrays=None, device="cpu"):
                             codebook_params=CodebookParams(dim=dim, codebook_size=K, **case.get("cb_extra", {})),
                             shared_codebook=shared, **case.get("vq_extra", {}), **case.get("rvq_extra", {}))
         cb = make_rvq_codebooks(Q, K, dim, case["cls"])
+        poison_(x, cb, case.get("nonfinite"))
         with torch.no_grad():
             for i, layer in enumerate(mod.layers):
                 layer._codebook.embeddings.copy_(cb[0 if shared else i][None])

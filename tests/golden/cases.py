@@ -134,6 +134,36 @@ CASES = [
     _vq("cfg5_S", 512, 65536, (1, 64, 512), "S"),
 ]
 
+# --- non-finite inputs: ATen's argmax treats NaN as the maximum and returns the FIRST NaN
+#     (utils/general.py:128 over codebooks.py:128-129,386): a row holding a NaN answers 0, a row holding +-inf the first code
+#     whose chain meets inf - inf, a code holding a NaN wins every row, a code holding an inf wins the rows on one side of it.
+_NF_X = dict(x=[[1, 5, "nan"], [2, 2, "inf"], [3, 2, "-inf"], [4, None, "inf"], [5, 0, "inf"], [5, 1, "-inf"], [6, 63, "nan"],
+                [130, 7, "nan"], [255, 0, "-inf"]])
+_NF_CB_NAN = dict(cb=[[0, 57, 4, "nan"], [0, 20, 9, "nan"]])
+_NF_CB_INF = dict(cb=[[0, 20, 4, "inf"]])
+CASES += [
+    _vq("nf_x_S", 64, 256, (4, 64, 64), "S", nonfinite=_NF_X),
+    _vq("nf_x_S_train", 64, 256, (4, 64, 64), "S", nonfinite=_NF_X, training=True),
+    _vq("nf_x_cos_S", 64, 256, (4, 64, 64), "S", nonfinite=_NF_X, use_cosine_sim=True),
+    _vq("nf_cb_nan_S", 64, 256, (4, 64, 64), "S", nonfinite=_NF_CB_NAN),
+    _vq("nf_cb_nan_cos_S", 64, 256, (4, 64, 64), "S", nonfinite=_NF_CB_NAN, use_cosine_sim=True),
+    _vq("nf_cb_inf_S", 64, 256, (4, 64, 64), "S", nonfinite=_NF_CB_INF),
+    _vq("nf_cb_inf_cos_S", 64, 256, (4, 64, 64), "S", nonfinite=_NF_CB_INF, use_cosine_sim=True),
+    _vq("nf_both_S", 64, 256, (4, 64, 64), "S", nonfinite=dict(x=_NF_X["x"], cb=_NF_CB_INF["cb"])),
+    _vq("nf_x_mh_S", 128, 128, (2, 64, 128), "S", heads=2, codebook_dim=64, separate_codebook_per_head=True,
+        nonfinite=dict(x=[[1, 5, "nan"], [2, 70, "inf"], [3, 64, "-inf"], [100, 127, "nan"]])),
+    _vq("nf_x_d256_S", 256, 1024, (2, 256, 256), "S",
+        nonfinite=dict(x=[[0, 255, "nan"], [2, 100, "inf"], [3, 101, "-inf"], [300, 0, "nan"], [511, 17, "inf"]])),
+    _vq("nf_x_d512_S", 512, 300, (2, 40, 512), "S", nonfinite=dict(x=[[1, 300, "nan"], [2, 2, "inf"], [79, 511, "-inf"]])),
+    _vq("nf_x_wide_S", 768, 300, (2, 40, 768), "S", nonfinite=dict(x=[[1, 700, "nan"], [2, 2, "inf"], [3, 600, "-inf"], [79, 5, "nan"]])),
+    _vq("nf_cb_wide_S", 768, 300, (2, 40, 768), "S", nonfinite=dict(cb=[[0, 33, 700, "nan"]])),
+    _rvq("nf_rvq_x_S", 64, 3, 128, (2, 64, 64), "S", nonfinite=dict(x=[[1, 5, "nan"], [2, 2, "inf"], [3, 2, "-inf"], [127, 63, "nan"]])),
+    _rvq("nf_rvq_x_S_train", 64, 3, 128, (2, 64, 64), "S", training=True,
+         nonfinite=dict(x=[[1, 5, "nan"], [2, 2, "inf"], [3, 2, "-inf"], [127, 63, "nan"]])),
+    _rvq("nf_rvq_cb_S", 64, 3, 128, (2, 64, 64), "S", nonfinite=dict(cb=[[1, 40, 3, "nan"]])),
+    _rvq("nf_rvq_cb_inf_S", 64, 3, 128, (2, 64, 64), "S", nonfinite=dict(cb=[[2, 40, 3, "inf"], [0, 7, 0, "-inf"]])),
+]
+
 CASES_BY_NAME = {c["name"]: c for c in CASES}
 
 

@@ -80,3 +80,22 @@ def seeded_projection_(mod, seed: int = 5150) -> None:
             fan_in = lin.weight.shape[1]
             lin.weight.copy_(torch.randn(tuple(lin.weight.shape), generator=g) / math.sqrt(fan_in))
             lin.bias.copy_(torch.randn(tuple(lin.bias.shape), generator=g) * 0.1)
+
+
+_VALUES = {"nan": float("nan"), "inf": float("inf"), "-inf": float("-inf")}
+
+
+def poison_(x: torch.Tensor, cb: torch.Tensor, spec) -> None:
+    """Non-finite entries written in place (the ``nonfinite`` field of a case): ``spec["x"]`` = [[row, dim | None, value]]
+    on the rows of ``x`` flattened to [-1, last dim] (dim None: the whole row), ``spec["cb"]`` = [[codebook, code, dim, value]]
+    on ``cb`` [h | Q, K, D]; value in "nan", "inf", "-inf"."""
+    if not spec:
+        return
+    rows = x.view(-1, x.shape[-1])
+    for row, dim, val in spec.get("x", []):
+        if dim is None:
+            rows[row, :] = _VALUES[val]
+        else:
+            rows[row, dim] = _VALUES[val]
+    for book, code, dim, val in spec.get("cb", []):
+        cb[book, code, dim] = _VALUES[val]

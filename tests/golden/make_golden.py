@@ -25,7 +25,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 from cases import CASES, LOSS_CASES  # noqa: E402
-from gen import CB_SEED, checksum, l2norm, make_codebook, make_rvq_codebooks, make_x, seeded_projection_  # noqa: E402
+from gen import CB_SEED, checksum, l2norm, make_codebook, make_rvq_codebooks, make_x, poison_, seeded_projection_  # noqa: E402
 
 
 def _import_reference():
@@ -81,12 +81,13 @@ def run_vq(ref, ref_cb, c):
     cb = make_codebook(h, K, d, c["cls"])
     if c.get("weights_regularization", "identity") == "l2norm":
         cb = l2norm(cb)
+    x = make_x(c["x_shape"], c["cls"])
+    poison_(x, cb, c.get("nonfinite"))
     with torch.no_grad():
         mod._codebook.embeddings.copy_(cb)
         mod._codebook.embed_avg.copy_(cb)
     if c.get("seeded_proj", False):
         seeded_projection_(mod)
-    x = make_x(c["x_shape"], c["cls"])
     stash = {}
 
     def hook(_m, _inp, out):
@@ -239,11 +240,12 @@ def run_rvq(ref, ref_cb, c):
     mod = ref.ResidualVQ(dim=dim, num_quantizers=Q, codebook_params=params, shared_codebook=shared,
                          **c.get("vq_extra", {}), **c.get("rvq_extra", {}))
     cbs = make_rvq_codebooks(Q, K, dim, c["cls"])
+    x = make_x(c["x_shape"], c["cls"])
+    poison_(x, cbs, c.get("nonfinite"))
     with torch.no_grad():
         for i, layer in enumerate(mod.layers):
             layer._codebook.embeddings.copy_(cbs[0 if shared else i][None])
             layer._codebook.embed_avg.copy_(cbs[0 if shared else i][None])
-    x = make_x(c["x_shape"], c["cls"])
     kwargs = {}
     if c["training"]:
         mod.train()

@@ -169,4 +169,4 @@ def load_golden(name: str):
 def checksum_close(t: torch.Tensor, ref, rtol=1e-6):
     t64 = t.detach().double().flatten()
     got = [float(t64.sum()), float(t64.abs().sum()), float(t64[0]), float(t64[-1])]
-    return np.allclose(got, ref, rtol=rtol, atol=1e-6), got
+    return np.allclose(got, ref, rtol=rtol, atol=1e-6, equal_nan=True), got

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from cases import CASES_BY_NAME
-from gen import make_codebook, make_rvq_codebooks, make_x
+from gen import make_codebook, make_rvq_codebooks, make_x, poison_
 from helpers import load_golden
 from oracle import ref_path
 
@@ -29,6 +29,50 @@ def test_c_oracle_indices_equal_reference(oracle, name):
     np.testing.assert_allclose(best, ref_best, rtol=2e-5, atol=2e-5)
     if c["cls"] == "Gdup":
         assert idx.max() < c["K"] // 2
+
+
+NONFINITE = ["nf_x_S", "nf_x_cos_S", "nf_cb_nan_S", "nf_cb_nan_cos_S", "nf_cb_inf_S", "nf_cb_inf_cos_S", "nf_both_S",
+             "nf_x_d256_S", "nf_x_d512_S", "nf_x_wide_S", "nf_cb_wide_S"]
+
+
+@pytest.mark.parametrize("name", NONFINITE)
+def test_c_oracle_nonfinite_rule_equals_reference(oracle, name):
+    """argmax treats NaN as the maximum and returns the FIRST one (utils/general.py:128 over codebooks.py:128-129,386):
+    the oracle's rule against indices and winning similarities captured from the reference on poisoned inputs."""
+    c = CASES_BY_NAME[name]
+    arrays, _ = load_golden(name)
+    x = make_x(c["x_shape"], c["cls"])
+    cb = make_codebook(1, c["K"], c["dim"], c["cls"])
+    poison_(x, cb, c["nonfinite"])
+    metric = oracle.DOT if c.get("use_cosine_sim", False) else oracle.EUCLID
+    idx, best = oracle.nearest(x.reshape(-1, c["dim"]).numpy(), cb[0].numpy(), metric)
+    np.testing.assert_array_equal(idx, arrays["idx"].reshape(-1).astype(np.int64))
+    ref_best = arrays["ref_best"].reshape(-1)
+    ref_best = ref_best if metric == oracle.DOT else -ref_best
+    assert np.array_equal(np.isnan(best), np.isnan(ref_best))
+    np.testing.assert_allclose(best, ref_best, rtol=2e-5, atol=2e-5)
+    assert np.isnan(best).any() or np.isinf(best).any()  # the case really exercises the rule
+    # and the packed keys keep it: a NaN similarity is the best key, the lowest index wins among NaNs
+    keys = oracle.pack_key(best, idx, metric)
+    b2, i2 = oracle.unpack_key(keys, metric)
+    np.testing.assert_array_equal(i2, idx)
+    assert np.array_equal(np.isnan(b2), np.isnan(best)) and np.array_equal(b2[~np.isnan(b2)], best[~np.isnan(best)])
+    nan_key = oracle.pack_key(np.array([np.nan], np.float32), np.array([7]), metric)
+    zero_key = oracle.pack_key(np.array([0.0 if metric == oracle.EUCLID else np.inf], np.float32), np.array([0]), metric)
+    assert nan_key[0] < zero_key[0]
+
+
+@pytest.mark.parametrize("name", ["nf_rvq_x_S", "nf_rvq_x_S_train", "nf_rvq_cb_S", "nf_rvq_cb_inf_S"])
+def test_c_oracle_nonfinite_rvq_equals_reference(oracle, name):
+    c = CASES_BY_NAME[name]
+    arrays, _ = load_golden(name)
+    x = make_x(c["x_shape"], c["cls"])
+    cbs = make_rvq_codebooks(c["Q"], c["K"], c["dim"], c["cls"])
+    poison_(x, cbs, c["nonfinite"])
+    with np.errstate(invalid="ignore"):
+        r = oracle.rvq_forward(x.reshape(-1, c["dim"]).numpy(), cbs.numpy(), oracle.EUCLID, training=c["training"])
+    np.testing.assert_array_equal(r["idx"], arrays["idx"].reshape(-1, c["Q"]).astype(np.int64))
+    np.testing.assert_allclose(r["out"].reshape(arrays["q_full"].shape), arrays["q_full"], atol=1e-5, rtol=0)
 
 
 @pytest.mark.parametrize("name", ["cfg1_G", "cfg2_G", "cos_G"])

@@ -39,6 +39,18 @@
 
 #include "../../include/vq_mi355x.h"
 
+// Build parts.  `hipcc ... vq_kernels.hip` (VQ_PART undefined) builds everything as ONE translation unit.  build.sh compiles
+// the same file once per part (-DVQ_PART=n, in parallel) and links the objects: every part sees the same templates, but only
+// its own launchers are defined -- and with them instantiated -- there; the other parts call them through the
+// vqi::part_* entry points declared below.
+//   0 C ABI, planners, small kernels (pack, scalar search, finalize, EMA)      4 search Dp = 512 + wave-pair kernel
+//   1 search Dp = 32 / 64         2 search Dp = 128                             5 similarity / softmax-statistics sweeps
+//   3 search Dp = 256 + persistent kernel + full slices of wide rows            6 fused cross-entropy backward
+#ifndef VQ_PART
+#define VQ_PART -1
+#endif
+#define VQ_OWN(part) (VQ_PART < 0 || VQ_PART == (part))
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -46,12 +58,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 #include "vq_common.inc"
+#if VQ_OWN(0)
 #include "vq_pack.inc"
+#endif
 #include "vq_search.inc"
 #include "vq_search_pair.inc"
 #include "vq_search_persist.inc"
 #include "vq_similarity.inc"
+#if VQ_OWN(0)
 #include "vq_finalize_ema.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -170,34 +186,12 @@ int launch_pair_t(const SearchParams &p, int H, int splits, hipStream_t s) {
     return 0;
 }
 
-int launch_pair(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+int launch_pair_any(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
     const bool eu = metric == VQ_METRIC_EUCLID;
     if (p.xt == 1) return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 1>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 1>(p, H, splits, s);
     if (p.xt == 2) return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 2>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 2>(p, H, splits, s);
     if (p.lse) return eu ? launch_pair_t<VQ_METRIC_EUCLID, true>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, true>(p, H, splits, s);
     return eu ? launch_pair_t<VQ_METRIC_EUCLID>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT>(p, H, splits, s);
-}
-
-// VQ_SINGLE_WAVE_512=1 in the environment selects the one-wave-per-row-block kernel for D > 256 (A/B measurements)
-bool use_pair512() {
-    static const bool off = getenv("VQ_SINGLE_WAVE_512") != nullptr;
-    return !off;
-}
-
-// The wave-pair kernel runs wave B one tile behind wave A: one extra step per sweep.  Worth it from 8 tiles per sweep on.
-bool pair_selected(int DP, int Q, int tiles_per_sweep) { return DP == 512 && Q == 1 && tiles_per_sweep >= 8 && use_pair512(); }
-
-// Plain inference call at Dp = 256 (one stage, no straight-through, no loss, aligned fp32 rows, >= 32 sub-tiles per sweep,
-// several row blocks per CU): persistent workgroups that copy block b's winners during block b + 1's sweep.
-// VQ_NO_PERSIST=1 in the environment keeps the one-block-per-workgroup kernel (A/B measurements).
-bool persist_selected(int DP, int waves, const SearchParams &p, int H, int splits, int cus) {
-    static const bool off = getenv("VQ_NO_PERSIST") != nullptr;
-    if (off || DP != 256 || waves != 8 || splits != 1 || p.Q != 1 || p.mode != kModeFused) return false;
-    if (p.ste || p.loss_part || p.lse || p.xt || !p.vec_x || !p.vec_fin || !p.out || p.D % 4) return false;
-    const int nsub = p.ntiles * sub_tiles(DP);
-    if (nsub < 32 || nsub > 96) return false;  // one row per sub-tile needs 32; beyond ~100 the finalize is < 1 % of a block
-    const long long nblk = (p.M + 32 * waves - 1) / (32 * waves);
-    return nblk * H >= 2ll * cus;  // at least two blocks per resident workgroup
 }
 
 template <int METRIC>
@@ -216,25 +210,6 @@ int launch_persist_t(const SearchParams &p, int H, int cus, hipStream_t s) {
     if (e != hipSuccess) return hip_fail(e, "vq_search_persist launch");
     return 0;
 }
-
-int launch_search(int DP, int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
-    {
-        const DevInfo &di = dev_info();
-        const int cus = di.ok && di.cus > 0 ? di.cus : 256;
-        if (persist_selected(DP, waves, p, H, splits, cus))
-            return metric == VQ_METRIC_EUCLID ? launch_persist_t<VQ_METRIC_EUCLID>(p, H, cus, s) : launch_persist_t<VQ_METRIC_DOT>(p, H, cus, s);
-    }
-    if (pair_selected(DP, p.Q, p.tiles_per_split)) return launch_pair(p, H, splits, metric, s);  // single stage: wave pairs
-    switch (DP) {
-        case 32: return waves == 8 ? launch_search_m<32, 8>(p, H, splits, metric, s) : launch_search_m<32, 4>(p, H, splits, metric, s);
-        case 64: return waves == 8 ? launch_search_m<64, 8>(p, H, splits, metric, s) : launch_search_m<64, 4>(p, H, splits, metric, s);
-        case 128: return waves == 8 ? launch_search_m<128, 8>(p, H, splits, metric, s) : launch_search_m<128, 4>(p, H, splits, metric, s);
-        case 256: return waves == 8 ? launch_search_m<256, 8>(p, H, splits, metric, s) : launch_search_m<256, 4>(p, H, splits, metric, s);
-        case 512: return launch_search_m<512, 4>(p, H, splits, metric, s);
-    }
-    return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
-}
-
 
 template <int DP, int WAVES, int METRIC, int MODE>
 int launch_aux_t(const AuxParams &p, int H, hipStream_t s) {
@@ -261,18 +236,6 @@ int launch_aux_m(const AuxParams &p, int H, int metric, int mode, hipStream_t s)
     return launch_aux_t<DP, WAVES, VQ_METRIC_DOT, kAuxStats>(p, H, s);
 }
 
-int launch_aux(int DP, const AuxParams &p, int H, int metric, int mode, hipStream_t s) {
-    switch (DP) {
-        case 32: return launch_aux_m<32, 4>(p, H, metric, mode, s);
-        case 64: return launch_aux_m<64, 4>(p, H, metric, mode, s);
-        case 128: return launch_aux_m<128, 4>(p, H, metric, mode, s);
-        case 256: return launch_aux_m<256, 4>(p, H, metric, mode, s);
-        case 512: return launch_aux_m<512, 4>(p, H, metric, mode, s);
-    }
-    return fail(VQ_E_UNSUPPORTED, "vq_sweep_aux: unsupported padded dim");
-}
-
-
 template <int DP, int METRIC>
 int launch_ce_bwd_t(const CeBwdParams &p, int H, hipStream_t s) {
     using G = Geo<DP, 4>;
@@ -292,6 +255,186 @@ template <int DP>
 int launch_ce_bwd_m(const CeBwdParams &p, int H, int metric, hipStream_t s) {
     if (metric == VQ_METRIC_EUCLID) return launch_ce_bwd_t<DP, VQ_METRIC_EUCLID>(p, H, s);
     return launch_ce_bwd_t<DP, VQ_METRIC_DOT>(p, H, s);
+}
+
+#ifndef VQ_EXP_WIDE_SLICE
+#define VQ_EXP_WIDE_SLICE 256
+#endif
+constexpr int kWideSlice = VQ_EXP_WIDE_SLICE;                // dims per slice: 512 (4-wave workgroups) or 256 (8-wave)
+constexpr int kWideWaves = kWideSlice == 512 ? 4 : 8;
+constexpr int kWideRows = 32 * kWideWaves;                   // rows per workgroup
+#ifndef VQ_EXP_WIDE_CHUNK_MB
+#define VQ_EXP_WIDE_CHUNK_MB 512
+#endif
+constexpr long long kWideChunkBytes = (long long)VQ_EXP_WIDE_CHUNK_MB << 20;  // accumulator workspace per (row chunk, code chunk)
+constexpr int kWideCodes = 4096;                    // codes per chunk
+
+template <int DP, int WIDE>
+int launch_wide_t(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, kWideWaves, VQ_METRIC_EUCLID, 0, false, 0, WIDE>(p, H, splits, s);
+    return launch_search_t<DP, kWideWaves, VQ_METRIC_DOT, 0, false, 0, WIDE>(p, H, splits, s);
+}
+
+// one slice of rows wider than 512 dims: WIDE = 1 a full slice (Dp = the slice width only), 2 / 3 the last slice
+template <int DP>
+int launch_wide_any(int wide, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    if (wide == 1) {
+        if constexpr (DP >= 256) return launch_wide_t<DP, 1>(p, H, splits, metric, s);
+        return fail(VQ_E_UNSUPPORTED, "vq_search: a full slice of wide rows is 256 (or 512) dims");
+    }
+    return wide == 3 ? launch_wide_t<DP, 3>(p, H, splits, metric, s) : launch_wide_t<DP, 2>(p, H, splits, metric, s);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// entry points of the build parts: declared everywhere, defined (= their kernels instantiated) in the owning part only
+// ------------------------------------------------------------------------------------------------
+namespace vqi {
+template <int DP> int part_search(int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s);
+template <int DP> int part_wide(int wide, const SearchParams &p, int H, int splits, int metric, hipStream_t s);
+template <int DP> int part_aux(const AuxParams &p, int H, int metric, int mode, hipStream_t s);
+template <int DP> int part_ce_bwd(const CeBwdParams &p, int H, int metric, hipStream_t s);
+int part_pair(const SearchParams &p, int H, int splits, int metric, hipStream_t s);
+int part_persist(const SearchParams &p, int H, int cus, int metric, hipStream_t s);
+#define VQ_DECLARE_PARTS(DP)                                                                                         \
+    template <> int part_search<DP>(int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s); \
+    template <> int part_wide<DP>(int wide, const SearchParams &p, int H, int splits, int metric, hipStream_t s);    \
+    template <> int part_aux<DP>(const AuxParams &p, int H, int metric, int mode, hipStream_t s);                    \
+    template <> int part_ce_bwd<DP>(const CeBwdParams &p, int H, int metric, hipStream_t s);
+VQ_DECLARE_PARTS(32)
+VQ_DECLARE_PARTS(64)
+VQ_DECLARE_PARTS(128)
+VQ_DECLARE_PARTS(256)
+VQ_DECLARE_PARTS(512)
+#undef VQ_DECLARE_PARTS
+
+#define VQ_DEFINE_SEARCH_PART(DP, W4)                                                                                 \
+    template <> int part_search<DP>(int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s) { \
+        return waves == 8 ? launch_search_m<DP, 8>(p, H, splits, metric, s) : launch_search_m<DP, W4>(p, H, splits, metric, s); \
+    }                                                                                                                 \
+    template <> int part_wide<DP>(int wide, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {    \
+        return launch_wide_any<DP>(wide, p, H, splits, metric, s);                                                    \
+    }
+#if VQ_OWN(1)
+VQ_DEFINE_SEARCH_PART(32, 4)
+VQ_DEFINE_SEARCH_PART(64, 4)
+#endif
+#if VQ_OWN(2)
+VQ_DEFINE_SEARCH_PART(128, 4)
+#endif
+#if VQ_OWN(3)
+VQ_DEFINE_SEARCH_PART(256, 4)
+int part_persist(const SearchParams &p, int H, int cus, int metric, hipStream_t s) {
+    return metric == VQ_METRIC_EUCLID ? launch_persist_t<VQ_METRIC_EUCLID>(p, H, cus, s) : launch_persist_t<VQ_METRIC_DOT>(p, H, cus, s);
+}
+#endif
+#if VQ_OWN(4)
+template <> int part_search<512>(int, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    return launch_search_m<512, 4>(p, H, splits, metric, s);
+}
+template <> int part_wide<512>(int wide, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+#if VQ_EXP_WIDE_SLICE == 512
+    return launch_wide_any<512>(wide, p, H, splits, metric, s);
+#else
+    (void)wide; (void)p; (void)H; (void)splits; (void)metric; (void)s;
+    return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
+#endif
+}
+int part_pair(const SearchParams &p, int H, int splits, int metric, hipStream_t s) { return launch_pair_any(p, H, splits, metric, s); }
+#endif
+#undef VQ_DEFINE_SEARCH_PART
+#if VQ_OWN(5)
+#define VQ_DEFINE_AUX_PART(DP) \
+    template <> int part_aux<DP>(const AuxParams &p, int H, int metric, int mode, hipStream_t s) { return launch_aux_m<DP, 4>(p, H, metric, mode, s); }
+VQ_DEFINE_AUX_PART(32)
+VQ_DEFINE_AUX_PART(64)
+VQ_DEFINE_AUX_PART(128)
+VQ_DEFINE_AUX_PART(256)
+VQ_DEFINE_AUX_PART(512)
+#undef VQ_DEFINE_AUX_PART
+#endif
+#if VQ_OWN(6)
+#define VQ_DEFINE_CE_PART(DP) \
+    template <> int part_ce_bwd<DP>(const CeBwdParams &p, int H, int metric, hipStream_t s) { return launch_ce_bwd_m<DP>(p, H, metric, s); }
+VQ_DEFINE_CE_PART(32)
+VQ_DEFINE_CE_PART(64)
+VQ_DEFINE_CE_PART(128)
+VQ_DEFINE_CE_PART(256)
+VQ_DEFINE_CE_PART(512)
+#undef VQ_DEFINE_CE_PART
+#endif
+}  // namespace vqi
+
+#if VQ_OWN(0)
+namespace vqi {
+thread_local char g_err[512] = "";
+}
+namespace {
+
+// VQ_SINGLE_WAVE_512=1 in the environment selects the one-wave-per-row-block kernel for D > 256 (A/B measurements)
+bool use_pair512() {
+    static const bool off = getenv("VQ_SINGLE_WAVE_512") != nullptr;
+    return !off;
+}
+
+// The wave-pair kernel runs wave B one tile behind wave A: one extra step per sweep.  Worth it from 8 tiles per sweep on.
+bool pair_selected(int DP, int Q, int tiles_per_sweep) { return DP == 512 && Q == 1 && tiles_per_sweep >= 8 && use_pair512(); }
+
+// Plain inference call at Dp = 256 (one stage, no straight-through, no loss, aligned fp32 rows, >= 32 sub-tiles per sweep,
+// several row blocks per CU): persistent workgroups that copy block b's winners during block b + 1's sweep.
+// VQ_NO_PERSIST=1 in the environment keeps the one-block-per-workgroup kernel (A/B measurements).
+bool persist_selected(int DP, int waves, const SearchParams &p, int H, int splits, int cus) {
+    static const bool off = getenv("VQ_NO_PERSIST") != nullptr;
+    if (off || DP != 256 || waves != 8 || splits != 1 || p.Q != 1 || p.mode != kModeFused) return false;
+    if (p.ste || p.loss_part || p.lse || p.xt || !p.vec_x || !p.vec_fin || !p.out || p.D % 4) return false;
+    const int nsub = p.ntiles * sub_tiles(DP);
+    if (nsub < 32 || nsub > 96) return false;  // one row per sub-tile needs 32; beyond ~100 the finalize is < 1 % of a block
+    const long long nblk = (p.M + 32 * waves - 1) / (32 * waves);
+    return nblk * H >= 2ll * cus;  // at least two blocks per resident workgroup
+}
+
+int launch_search(int DP, int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    {
+        const DevInfo &di = dev_info();
+        const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+        if (persist_selected(DP, waves, p, H, splits, cus))
+            return vqi::part_persist(p, H, cus, metric, s);
+    }
+    if (pair_selected(DP, p.Q, p.tiles_per_split)) return vqi::part_pair(p, H, splits, metric, s);  // single stage: wave pairs
+    switch (DP) {
+        case 32: return vqi::part_search<32>(waves, p, H, splits, metric, s);
+        case 64: return vqi::part_search<64>(waves, p, H, splits, metric, s);
+        case 128: return vqi::part_search<128>(waves, p, H, splits, metric, s);
+        case 256: return vqi::part_search<256>(waves, p, H, splits, metric, s);
+        case 512: return vqi::part_search<512>(waves, p, H, splits, metric, s);
+    }
+    return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
+}
+
+
+int launch_aux(int DP, const AuxParams &p, int H, int metric, int mode, hipStream_t s) {
+    switch (DP) {
+        case 32: return vqi::part_aux<32>(p, H, metric, mode, s);
+        case 64: return vqi::part_aux<64>(p, H, metric, mode, s);
+        case 128: return vqi::part_aux<128>(p, H, metric, mode, s);
+        case 256: return vqi::part_aux<256>(p, H, metric, mode, s);
+        case 512: return vqi::part_aux<512>(p, H, metric, mode, s);
+    }
+    return fail(VQ_E_UNSUPPORTED, "vq_sweep_aux: unsupported padded dim");
+}
+
+
+// one slice of a wide-row sweep, by the padded width of the slice
+int launch_wide(int wide, int DP, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
+    switch (DP) {
+        case 32: return vqi::part_wide<32>(wide, p, H, splits, metric, s);
+        case 64: return vqi::part_wide<64>(wide, p, H, splits, metric, s);
+        case 128: return vqi::part_wide<128>(wide, p, H, splits, metric, s);
+        case 256: return vqi::part_wide<256>(wide, p, H, splits, metric, s);
+        case 512: return vqi::part_wide<512>(wide, p, H, splits, metric, s);
+    }
+    return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
 }
 
 bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -419,17 +562,6 @@ long long plan_main_tail(int DP, int H, long long M, int K, int D, int cus) {
 // kWideSlice dims: slice j continues the chains slice j - 1 left in the workspace (the accumulators' own fragment layout: every
 // lane reads back exactly the 16-byte pieces it wrote, coalesced), and the last slice closes them with the norms and runs
 // the argmin into packed keys.  The workspace holds the chains of one (row chunk) x (code chunk) at a time.
-#ifndef VQ_EXP_WIDE_SLICE
-#define VQ_EXP_WIDE_SLICE 256
-#endif
-constexpr int kWideSlice = VQ_EXP_WIDE_SLICE;                // dims per slice: 512 (4-wave workgroups) or 256 (8-wave)
-constexpr int kWideWaves = kWideSlice == 512 ? 4 : 8;
-constexpr int kWideRows = 32 * kWideWaves;                   // rows per workgroup
-#ifndef VQ_EXP_WIDE_CHUNK_MB
-#define VQ_EXP_WIDE_CHUNK_MB 512
-#endif
-constexpr long long kWideChunkBytes = (long long)VQ_EXP_WIDE_CHUNK_MB << 20;  // accumulator workspace per (row chunk, code chunk)
-constexpr int kWideCodes = 4096;                    // codes per chunk
 
 struct WidePlan {
     int nd;            // slices
@@ -459,26 +591,6 @@ int wide_last_dims(int D) { return D - (D - 1) / kWideSlice * kWideSlice; }
 long long wide_last_image_floats(int K, int D) {
     const int DP = padded_dim(wide_last_dims(D));
     return (long long)round_up(K, kTileCodes * sub_tiles(DP)) * (DP + 4) + kPackSlack;
-}
-
-template <int DP, int WIDE>
-int launch_wide_t(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
-    if (metric == VQ_METRIC_EUCLID) return launch_search_t<DP, kWideWaves, VQ_METRIC_EUCLID, 0, false, 0, WIDE>(p, H, splits, s);
-    return launch_search_t<DP, kWideWaves, VQ_METRIC_DOT, 0, false, 0, WIDE>(p, H, splits, s);
-}
-
-template <int WIDE>
-int launch_wide_last(int DP, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
-    switch (DP) {
-        case 32: return launch_wide_t<32, WIDE>(p, H, splits, metric, s);
-        case 64: return launch_wide_t<64, WIDE>(p, H, splits, metric, s);
-        case 128: return launch_wide_t<128, WIDE>(p, H, splits, metric, s);
-        case 256: return launch_wide_t<256, WIDE>(p, H, splits, metric, s);
-        case 512:
-            if constexpr (kWideSlice == 512) return launch_wide_t<512, WIDE>(p, H, splits, metric, s);
-            break;
-    }
-    return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
 }
 
 bool wide_workspace_ok(const vq_args *a) {
@@ -578,9 +690,7 @@ int run_wide(const vq_args *a, long long idx_offset, long long *keys, float *sim
                     p.sims_rs = sims_rs; p.sims_hs = sims_hs;
                     p.vec_s = (a->K % 4 == 0 && sims_rs % 4 == 0 && sims_hs % 4 == 0 && aligned16(sims)) ? 1 : 0;
                 }
-                const int rc = !last ? launch_wide_t<kWideSlice, 1>(p, a->H, splits, a->metric, s)
-                               : sims ? launch_wide_last<3>(DP, p, a->H, splits, a->metric, s)
-                                      : launch_wide_last<2>(DP, p, a->H, splits, a->metric, s);
+                const int rc = launch_wide(!last ? 1 : (sims ? 3 : 2), DP, p, a->H, splits, a->metric, s);
                 if (rc) return rc;
             }
         }
@@ -1136,11 +1246,11 @@ int vq_ce_backward_f32(const vq_args *a, const float *lse, const float *target_l
     p.gx = grad_x; p.gx_rs = gx_rs; p.gx_hs = gx_hs;
     hipStream_t s = (hipStream_t)stream;
     switch (DP) {
-        case 32: return launch_ce_bwd_m<32>(p, a->H, a->metric, s);
-        case 64: return launch_ce_bwd_m<64>(p, a->H, a->metric, s);
-        case 128: return launch_ce_bwd_m<128>(p, a->H, a->metric, s);
-        case 256: return launch_ce_bwd_m<256>(p, a->H, a->metric, s);
-        case 512: return launch_ce_bwd_m<512>(p, a->H, a->metric, s);
+        case 32: return vqi::part_ce_bwd<32>(p, a->H, a->metric, s);
+        case 64: return vqi::part_ce_bwd<64>(p, a->H, a->metric, s);
+        case 128: return vqi::part_ce_bwd<128>(p, a->H, a->metric, s);
+        case 256: return vqi::part_ce_bwd<256>(p, a->H, a->metric, s);
+        case 512: return vqi::part_ce_bwd<512>(p, a->H, a->metric, s);
     }
     return fail(VQ_E_UNSUPPORTED, "vq_ce_backward: unsupported padded dim");
 }
@@ -1165,3 +1275,4 @@ int vq_nearest_f32(const vq_args *a, void *stream) {
 int vq_residual_f32(const vq_args *a, void *stream) { return vq_quantize_f32(a, stream); }
 
 }  // extern "C"
+#endif  // VQ_OWN(0)

@@ -181,6 +181,8 @@ class Codebook(nn.Module):
         """Identity of the code values: storage, in-place version counter (``copy_`` / ``load_state_dict`` / optimizer steps
         bump it) and an epoch for writes the counter cannot see (``.data`` index writes, the native EMA kernel)."""
         e = self.embeddings
+        if e.is_inference():  # built / loaded under torch.inference_mode(): no version counter -> never reuse a packed image
+            return (e.data_ptr(), object(), self._packed_epoch, e.device, tuple(e.shape))
         return (e.data_ptr(), e._version, self._packed_epoch, e.device, tuple(e.shape))
 
     def invalidate_packed(self):

@@ -36,12 +36,21 @@ class GraphedForward:
         torch.cuda.synchronize(example.device)
         # the modules cache the packed image of an unchanged codebook; the graph must contain the pack itself, so that a
         # replay reads the weights of its own time (in-place updates need no re-capture): drop the caches before capturing
-        for m in module.modules():
-            if hasattr(m, "invalidate_packed"):
-                m.invalidate_packed()
+        self._drop_packed_caches()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = module(self.static_in, **forward_kwargs)
+        # the capturing forward refilled those caches with tensors from the graph's private pool whose pack kernels were only
+        # RECORDED: until the first replay they hold uninitialised memory.  Drop them again, so that an eager module(x)
+        # (e.g. the fallback for a batch shape the graph was not captured for) packs for itself.
+        self._drop_packed_caches()
+
+    def _drop_packed_caches(self):
+        for m in self.module.modules():
+            if hasattr(m, "invalidate_packed"):
+                m.invalidate_packed()
+            if hasattr(m, "_stage_cache"):
+                m._stage_cache = None
 
     def __call__(self, x: torch.Tensor):
         if x.shape != self.static_in.shape or x.dtype != self.static_in.dtype:

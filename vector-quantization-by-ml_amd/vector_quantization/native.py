@@ -202,6 +202,15 @@ def pack_codebooks(cb: torch.Tensor, metric: int) -> torch.Tensor:
     return packed
 
 
+def _check_packed(packed: torch.Tensor, n: int, K: int, D: int, device) -> None:
+    """A caller-cached image must be THE image of these codebooks' shape: the kernels take its row stride from K and D and
+    read it through a buffer descriptor sized by vq_packed_floats -- a stale or foreign image would be read out of bounds."""
+    if (packed.dtype != torch.float32 or not packed.is_contiguous() or packed.device != device
+            or packed.numel() != n * packed_floats(K, D) or packed.shape[-1] != packed_floats(K, D)):
+        raise ValueError(f"packed image {tuple(packed.shape)} {packed.dtype} on {packed.device} does not belong to "
+                         f"{n} codebook(s) of K={K}, D={D} on {device} (expected [{n}, {packed_floats(K, D)}] contiguous fp32)")
+
+
 def _workspace(H: int, M: int, Q: int, device, K: int = 0, D: int = 0) -> torch.Tensor:
     nbytes = int(load().vq_workspace_bytes(H, M, Q))
     if D > 512:  # rows wider than 512 dims: room for the distance chains carried between the slices of the sweep
@@ -251,6 +260,7 @@ def quantize(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, ste: bo
     dev = x.device
     if packed is None:
         packed = pack_codebooks(cb, metric)
+    _check_packed(packed, Hc * Qc, K, D, dev)
     pf = packed.shape[-1]
     x_rs, x_hs = _row_strides(x)
     if idx is None:
@@ -314,6 +324,7 @@ def search_keys(x: torch.Tensor, cb: torch.Tensor, keys: torch.Tensor, *, metric
     assert keys.shape == (H, M) and keys.is_contiguous()
     if packed is None:
         packed = pack_codebooks(cb, metric)
+    _check_packed(packed, H, K, D, x.device)
     x_rs, x_hs = _row_strides(x)
     a = VqArgs()
     a.H, a.Q, a.M, a.K, a.D, a.metric, a.flags = H, 1, M, K, D, metric, flags
@@ -414,6 +425,7 @@ def _aux_args(x: torch.Tensor, cb: torch.Tensor, metric: int, packed, flags: int
     assert Hc == H and Dc == D
     if packed is None:
         packed = pack_codebooks(cb, metric)
+    _check_packed(packed, H, K, D, x.device)
     x_rs, x_hs = _row_strides(x)
     a = VqArgs()
     a.H, a.Q, a.M, a.K, a.D, a.metric, a.flags = H, 1, M, K, D, metric, flags

@@ -29,16 +29,26 @@ LossBreakdown = namedtuple(
 
 def _cached_zeros(module, attr: str, shape, device) -> torch.Tensor:
     """A persistent all-zero fp32 tensor for the loss an inference forward returns (the reference allocates one per call,
-    i.e. a fill kernel per forward).  Re-created if the caller modified the previous one in place."""
+    i.e. a fill kernel per forward).  Re-created if the caller modified the previous one in place; successive inference
+    forwards return the SAME tensor object until then.  The tensor is created outside inference mode so that it keeps a
+    version counter (an inference tensor has none: ``torch.inference_mode()`` is the standard serving idiom)."""
     if torch.compiler.is_compiling():
         return torch.zeros(shape, dtype=torch.float32, device=device)
     entry = getattr(module, attr, None)
     if (entry is None or entry[0].device != device or tuple(entry[0].shape) != tuple(shape)
             or entry[0]._version != entry[1]):
-        t = torch.zeros(shape, dtype=torch.float32, device=device)
+        with torch.inference_mode(False), torch.no_grad():
+            t = torch.zeros(shape, dtype=torch.float32, device=device)
         entry = (t, t._version)
         setattr(module, attr, entry)
     return entry[0]
+
+
+def _stochastic_sampling_requested(params: CodebookParams) -> bool:
+    """Gumbel-max code sampling asked for (the rule of Codebook._stochastic_requested, on the config before it is built)."""
+    g = params.gumbel_params
+    g = asdict(g) if hasattr(g, "__dataclass_fields__") else dict(g or {})
+    return bool(g.get("training", True) and g.get("stochastic", False) and g.get("temperature", 1.0) > 0)
 
 
 def _world_is_distributed() -> bool:
@@ -128,7 +138,8 @@ class VectorQuantize(nn.Module):
                                orthogonal_reg=orthogonal_reg_weight > 0.0, diversity_loss=codebook_diversity_loss_weight > 0.0,
                                in_place_codebook_optimizer=in_place_codebook_optimizer is not None,
                                learnable_codebook=codebook_params.learnable_codebook,
-                               initialization_by_kmeans=codebook_params.initialization_by_kmeans)
+                               initialization_by_kmeans=codebook_params.initialization_by_kmeans,
+                               stochastic_sampling=_stochastic_sampling_requested(codebook_params))
             bad = [k for k, v in unsupported.items() if v]
             if bad:
                 raise NotImplementedError(f"a sharded codebook supports the search / quantize step / EMA update only, not {bad}")

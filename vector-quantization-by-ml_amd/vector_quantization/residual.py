@@ -308,6 +308,10 @@ class GroupedResidualVQ(nn.Module):
         """[G, Q, K, d] natural codebooks + packed images of the one fused launch, rebuilt only when some codes changed."""
         cbs = [layer._codebook for rvq in self.rvqs for layer in rvq.layers]
         backend = search.get_backend()
+        if torch.compiler.is_compiling():  # traced: stack and pack are nodes of the graph (no identity-keyed cache in a trace)
+            codes = torch.stack([torch.stack([layer._codebook.embeddings.detach()[0] for layer in rvq.layers], dim=0)
+                                 for rvq in self.rvqs], dim=0).contiguous()
+            return codes, (backend.pack(codes, cbs[0].metric) if getattr(backend, "uses_packed", False) else None)
         key = (tuple(cb.codes_state() for cb in cbs), cbs[0].metric, getattr(backend, "name", None))
         if self._stage_cache is None or self._stage_cache[0] != key:
             with torch.no_grad():

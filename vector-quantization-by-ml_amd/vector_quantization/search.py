@@ -22,8 +22,20 @@ LSE_MAX_DIM = 512  # vq_quantize_lse_f32: rows of one launch
 
 
 def _want_deterministic(dim: int) -> bool:
-    """torch.use_deterministic_algorithms(True) selects the reproducible EMA accumulation (rows of up to 2048 dims)."""
-    return torch.are_deterministic_algorithms_enabled() and dim <= 2048
+    """torch.use_deterministic_algorithms(True) selects the reproducible EMA accumulation (rows of up to 2048 dims).
+    Wider rows only have the float-atomic kernel: torch's own convention applies -- raise, or warn under ``warn_only``."""
+    if not torch.are_deterministic_algorithms_enabled():
+        return False
+    if dim <= 2048:
+        return True
+    msg = (f"the EMA statistics of rows wider than 2048 dims (got {dim}) are accumulated with float atomics and have no "
+           "deterministic implementation; turn torch.use_deterministic_algorithms off (or use warn_only=True) for this step")
+    if torch.is_deterministic_algorithms_warn_only_enabled():
+        import warnings
+
+        warnings.warn(msg)
+        return False
+    raise RuntimeError(msg)
 
 
 class _NativeBackend:
