@@ -462,3 +462,65 @@ def test_inputs_beyond_2_31_elements(M, K, D):
     assert torch.equal(a["out"], s["out"])
     del x, a, s
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kind", ["vq", "rvq", "grvq"])
+def test_eager_forward_right_after_graph_capture(oracle, kind):
+    """the capturing forward refills the packed-image caches with tensors from the graph's private pool whose pack
+    kernels were only recorded.  An eager module(x) BEFORE the first replay (e.g. the fallback for another batch shape) must
+    not search that uninitialised memory."""
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(1)
+    if kind == "vq":
+        mod = vq.VectorQuantize(dim=64, codebook_params=CodebookParams(dim=64, codebook_size=256))
+    elif kind == "rvq":
+        mod = vq.ResidualVQ(dim=64, num_quantizers=3, codebook_params=CodebookParams(dim=64, codebook_size=128))
+    else:
+        mod = vq.GroupedResidualVQ(dim=64, groups=2, num_quantizers=2, codebook_params=CodebookParams(dim=32, codebook_size=64))
+    mod = mod.to(DEV).eval()
+    fast = vq.GraphedForward(mod, torch.randn(8, 64, 64, device=DEV))
+    x = torch.randn(5, 40, 64, device=DEV)  # another shape: eager fallback, no replay has happened yet
+    with torch.no_grad():
+        q, idx, _ = mod(x)
+    torch.cuda.synchronize()
+    # the codes the search saw must be the module's codes: every output row is the sum of codebook rows at its indices
+    if kind == "vq":
+        want = mod._codebook.embeddings[0][idx]
+    elif kind == "rvq":
+        want = sum(layer._codebook.embeddings[0][idx[..., i]] for i, layer in enumerate(mod.layers))
+    else:
+        want = torch.cat([sum(layer._codebook.embeddings[0][idx[g][..., i]] for i, layer in enumerate(rvq.layers))
+                          for g, rvq in enumerate(mod.rvqs)], dim=-1)
+    torch.testing.assert_close(q, want, rtol=0, atol=1e-6)
+    flat = x.reshape(-1, 64).cpu().numpy()
+    if kind == "vq":
+        ri, _ = oracle.nearest(flat, mod._codebook.embeddings[0].cpu().numpy(), oracle.EUCLID)
+        assert np.array_equal(idx.reshape(-1).cpu().numpy(), ri)
+    q2, i2, _ = fast(torch.randn(8, 64, 64, device=DEV))  # and the graph still replays
+    assert torch.isfinite(q2).all()
+
+
+@pytest.mark.parametrize("kind", ["vq", "rvq", "grvq"])
+def test_eval_forward_under_inference_mode(kind):
+    """torch.inference_mode() is the standard serving idiom; fresh modules, first call inside it."""
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams
+
+    torch.manual_seed(2)
+    if kind == "vq":
+        mod = vq.VectorQuantize(dim=64, codebook_params=CodebookParams(dim=64, codebook_size=256))
+    elif kind == "rvq":
+        mod = vq.ResidualVQ(dim=64, num_quantizers=3, codebook_params=CodebookParams(dim=64, codebook_size=128))
+    else:
+        mod = vq.GroupedResidualVQ(dim=64, groups=2, num_quantizers=2, codebook_params=CodebookParams(dim=32, codebook_size=64))
+    mod = mod.to(DEV).eval()
+    x = torch.randn(4, 50, 64, device=DEV)
+    with torch.inference_mode():
+        q1, i1, l1 = mod(x)
+        q2, i2, l2 = mod(x)
+    with torch.no_grad():
+        q3, i3, l3 = mod(x)
+    assert torch.equal(i1, i2) and torch.equal(i1, i3) and torch.equal(q1, q3)
+    assert float(l1.sum()) == 0.0 and float(l3.sum()) == 0.0

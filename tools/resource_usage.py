@@ -20,25 +20,31 @@ def main():
     if "--filter" in args:
         flt = args[args.index("--filter") + 1]
     extra = [a for a in args if a not in ("--spills", "--filter", flt)]
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-value", "-c",
-           "-Rpass-analysis=kernel-resource-usage", SRC, "-o", "/tmp/vq_resusage.o", *extra]
-    err = subprocess.run(cmd, capture_output=True, text=True).stderr
+    base = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-value", "-Wno-unused-function",
+            "-c", "-Rpass-analysis=kernel-resource-usage", SRC]
+    # the build parts of vq_kernels.hip compile in parallel (every kernel belongs to exactly one part)
+    procs = [subprocess.Popen(base + [f"-DVQ_PART={part}", "-o", f"/tmp/vq_resusage_{part}.o", *extra], stderr=subprocess.PIPE,
+                              text=True) for part in range(7)]
+    err = "".join(p.communicate()[1] for p in procs)
+    if any(p.returncode for p in procs):
+        sys.stderr.write(err[-4000:])
+        sys.exit(1)
     blocks = re.split(r"remark: [^\n]*Function Name: ", err)[1:]
     names = [b.split("\n")[0].strip() for b in blocks]
     dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
-    print(f"{'kernel':90s} VGPR AGPR spill scratch occ   LDS")
+    print(f"{'kernel':90s} VGPR AGPR spill scratch occ   LDS SGPR sspill")
     for b, n in zip(blocks, dem):
         def g(k):
             m = re.search(k + r": (\d+)", b)
             return int(m.group(1)) if m else -1
         n = n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-        row = (g("VGPRs"), g("AGPRs"), g("VGPR Spill"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"),
-               g(r"LDS Size \[bytes/block\]"))
+        row = (g("VGPRs"), g("AGPRs"), g("VGPRs Spill"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"),
+               g(r"LDS Size \[bytes/block\]"), g("TotalSGPRs"), g("SGPRs Spill"))
         if only_spills and row[2] <= 0 and row[3] <= 0:
             continue
         if flt and flt not in n:
             continue
-        print(f"{n[:90]:90s} {row[0]:4d} {row[1]:4d} {row[2]:5d} {row[3]:7d} {row[4]:3d} {row[5]:5d}")
+        print(f"{n[:90]:90s} {row[0]:4d} {row[1]:4d} {row[2]:5d} {row[3]:7d} {row[4]:3d} {row[5]:5d} {row[6]:4d} {row[7]:6d}")
 
 
 if __name__ == "__main__":

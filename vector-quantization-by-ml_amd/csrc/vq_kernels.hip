@@ -186,6 +186,7 @@ int launch_pair_t(const SearchParams &p, int H, int splits, hipStream_t s) {
     return 0;
 }
 
+#if VQ_OWN(4)  // (not a template: defining it instantiates the wave-pair kernels)
 int launch_pair_any(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
     const bool eu = metric == VQ_METRIC_EUCLID;
     if (p.xt == 1) return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 1>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 1>(p, H, splits, s);
@@ -193,6 +194,7 @@ int launch_pair_any(const SearchParams &p, int H, int splits, int metric, hipStr
     if (p.lse) return eu ? launch_pair_t<VQ_METRIC_EUCLID, true>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, true>(p, H, splits, s);
     return eu ? launch_pair_t<VQ_METRIC_EUCLID>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT>(p, H, splits, s);
 }
+#endif
 
 template <int METRIC>
 int launch_persist_t(const SearchParams &p, int H, int cus, hipStream_t s) {
@@ -468,6 +470,7 @@ void fill_search_params(SearchParams &p, const vq_args *a) {
     p.tiles_per_split = p.ntiles;
     p.key_hs = a->M;
     p.pk_bytes = (unsigned)(vq_packed_floats(a->K, a->D) * 4);
+
     p.ste = (a->flags & VQ_F_STE) ? 1 : 0;
     p.xt = (a->flags & VQ_F_X_F16) ? 1 : ((a->flags & VQ_F_X_BF16) ? 2 : 0);
     p.vec_x = (a->D % 4 == 0 && a->x_rs % 4 == 0 && a->x_hs % 4 == 0 &&
@@ -809,6 +812,8 @@ int vq_pack_codebooks_f32(const float *cb, int n_codebooks, int64_t cb_stride, i
             hipLaunchKernelGGL(vq_pack_kernel, dim3(Kp / 64 + 1, n_codebooks), dim3(64), 0, s, cb, (long long)cb_stride, K, Kp,
                                D, j * kWideSlice, dp, metric, packed + (long long)j * wide_image_floats(K), pk_stride);
         }
+        hipLaunchKernelGGL(vq_pack_flag_kernel, dim3(n_codebooks), dim3(256), 0, s, packed, pk_stride, K, kWideSlice + 4, kWideSlice,
+                           nd, wide_image_floats(K), wide_last_image_floats(K, D));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "vq_pack launch");
         return 0;
@@ -817,6 +822,8 @@ int vq_pack_codebooks_f32(const float *cb, int n_codebooks, int64_t cb_stride, i
     // grid covers Kp rows plus at least one extra block whose threads zero the over-copy slack
     hipLaunchKernelGGL(vq_pack_kernel, dim3(Kp / 64 + 1, n_codebooks), dim3(64), 0, s, cb, (long long)cb_stride, K, Kp,
                        D, 0, DP, metric, packed, pk_stride);
+    hipLaunchKernelGGL(vq_pack_flag_kernel, dim3(n_codebooks), dim3(256), 0, s, packed, pk_stride, K, DP + 4, DP, 1, pk_stride,
+                       (long long)vq_packed_floats(K, D));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "vq_pack launch");
     return 0;
