@@ -323,46 +323,57 @@ def run_workload(name, args, device, rank, world, want_parity):
     return value, elapsed / args.steps * 1e3, roof, parity, w
 
 
-def sharded_k65536(device, rank, world, steps=5):
+def sharded_k65536(device, rank, world, steps=10):
     """BASELINE configs[4]: K=65536, D=512 sharded over the ranks; both exchange variants (RCCL MIN all-reduce of the
-    packed keys, one-hop all-gather + local min)."""
+    packed-key planes, one-hop all-gather + MIN in the finalize), M = 8192 and M = 65536, each with a
+    per-phase breakdown (search / exchange / finalize device time, host enqueue time per step) so that a measured
+    scaling factor can be explained."""
     from vector_quantization.sharded import ShardedCodebookSearch
 
-    K, D, M = 65536, 512, 8192
+    K, D = 65536, 512
     g = torch.Generator().manual_seed(99)
     kl = K // world
     full = torch.randn((K, D), generator=g)
-    x = torch.randn((M, D), generator=torch.Generator().manual_seed(1234)).to(device)
     shard = full[rank * kl:(rank + 1) * kl].to(device)
     table = full.to(device)  # replicated gather table (128 MiB)
-    res = {}
-    for mode in ("all_reduce", "all_gather"):
-        s = ShardedCodebookSearch(shard, full_codebook=table, reduction=mode)
-        for _ in range(3):
-            s(x)
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            out, idx, best, _ = s(x)
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        el = time.perf_counter() - t0
-        t = torch.tensor([el], device=device)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-        res[mode] = dict(value=round(M * steps / el, 1), ms_per_step=round(el / steps * 1e3, 3), idx_checksum=int(idx.sum().item()))
-        if world == 1:
-            break  # no exchange at N = 1: the two variants are the same launches
-    best_mode = max(res, key=lambda m: res[m]["value"])
-    return dict(value=res[best_mode]["value"], unit="vectors/s", n_gpus=world, ms_per_step=res[best_mode]["ms_per_step"],
-                reduction=best_mode, variants=res,
-                roofline_frac=round(2.0 * K * D * res[best_mode]["value"] / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                config="K=65536 D=512 M=8192 tokens replicated, codebook sharded K/N per GPU, 8-byte packed (distance, index) keys "
-                       "reduced over the ranks, replicated gather table")
+    del full
+    by_m = {}
+    for M in (8192, 65536):
+        x = torch.randn((M, D), generator=torch.Generator().manual_seed(1234)).to(device)
+        res = {}
+        for mode in ("all_reduce", "all_gather"):
+            s = ShardedCodebookSearch(shard, full_codebook=table, reduction=mode)
+            for _ in range(3):
+                s(x)
+            torch.cuda.synchronize(device)
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out, idx, best, _ = s(x)
+            torch.cuda.synchronize(device)
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            t = torch.tensor([el], device=device)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            res[mode] = dict(value=round(M * steps / el, 1), ms_per_step=round(el / steps * 1e3, 3), idx_checksum=int(idx.sum().item()),
+                             phases=s.profile_phases(x, steps=steps))
+            if world == 1:
+                break  # no exchange at N = 1: the two variants are the same launches
+        best_mode = max(res, key=lambda m: res[m]["value"])
+        by_m[M] = dict(value=res[best_mode]["value"], ms_per_step=res[best_mode]["ms_per_step"], reduction=best_mode, variants=res,
+                       roofline_frac=round(2.0 * K * D * res[best_mode]["value"] / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+        del x
+    head = by_m[8192]
+    return dict(value=head["value"], unit="vectors/s", n_gpus=world, ms_per_step=head["ms_per_step"], reduction=head["reduction"],
+                variants=head["variants"], roofline_frac=head["roofline_frac"], m65536=by_m[65536],
+                config="K=65536 D=512 tokens replicated (M = 8192; m65536: M = 65536), codebook sharded K/N per GPU; per step ONE "
+                       "search launch (K split into key planes, no init, no atomics), ONE exchange of the 8-byte packed "
+                       "(distance, index) keys, ONE finalize launch (MIN over the candidate planes + gather from the replicated "
+                       "table); M >= 32768: two halves, the first half's exchange under the second half's search")
 
 
 def main():
@@ -385,22 +396,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     # rehearsal knobs (1-GPU box): all ranks on cuda:0 over gloo, to exercise the N > 1 code path
     one_device = os.environ.get("VQ_BENCH_ONE_DEVICE", "0") == "1"
     backend = os.environ.get("VQ_BENCH_BACKEND", "nccl")
-    device = torch.device("cuda:0" if one_device else f"cuda:{local_rank}")
-    torch.cuda.set_device(device)
     if world > 1:
+        # the rendezvous comes FIRST: no HIP call (not even torch.cuda.is_available(), which initialises the runtime) has
+        # been made in this process when the process group is created; the device is bound right after
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
 
         tmo = datetime.timedelta(seconds=180)  # a collective that cannot complete fails the run instead of hanging it
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=tmo)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+    if torch.cuda.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    device = torch.device("cuda:0" if one_device else f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.barrier(device_ids=[device.index] if backend == "nccl" else None)  # first collective: RCCL binds to this device
 
     from vector_quantization import native
 

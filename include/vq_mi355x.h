@@ -139,10 +139,24 @@ int vq_keys_init(int64_t *keys, int64_t n, void *stream);
 int vq_search_keys_f32(const vq_args *a, int64_t idx_offset, int64_t *keys, void *stream);
 
 /*
+ * The same search without the init launch and without atomics: when the library splits K over workgroups (few rows: the
+ * chip would not be full otherwise), split z STORES its winners into plane z of `keys` [vq_key_planes(a)][H][M]; the
+ * winner of a row is the MIN over the planes -- and over the planes of the other shards, which is what the exchange of
+ * the sharded path transports and vq_finalize_key_planes_f32 reduces.  vq_key_planes is host arithmetic (same arguments
+ * as the search call, current device's CU count).  Rows wider than 512 dims / VQ_F_FORCE_SIMPLE: one plane, initialised
+ * and combined inside the call.
+ */
+int vq_key_planes(const vq_args *a);
+int vq_search_key_planes_f32(const vq_args *a, int64_t idx_offset, int64_t *keys, void *stream);
+
+/*
  * Step 2: decode the (reduced) keys and finish: idx/best, gather from the natural codebook `a->cb`
  * (indexed by the GLOBAL code index), straight-through, sq_err.  Q == 1.
+ * vq_finalize_key_planes_f32: `keys` holds n_planes candidate planes [n_planes][H][M] (K splits x shards, e.g. the
+ * all-gathered planes of every rank); the MIN over the planes is taken on the fly.
  */
 int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream);
+int vq_finalize_key_planes_f32(const vq_args *a, const int64_t *keys, int n_planes, void *stream);
 
 /*
  * Backward of vq_quantize_f32 with respect to x (the autograd of the quantize step, vector_quantize_pytorch.py:261-279,

@@ -79,6 +79,8 @@ class OracleBackend:
 
     @staticmethod
     def finalize_keys(x, table, keys, *, metric):
+        if keys.dim() == 3:  # candidate planes: the winner is the MIN
+            keys = keys.amin(dim=0)
         _best, idx = vq_oracle.unpack_key(keys.numpy(), metric)
         idx = torch.from_numpy(idx)
         return table[torch.arange(table.shape[0])[:, None], idx], idx
@@ -151,12 +153,20 @@ class OracleShardOps:
         return torch.from_numpy(vq_oracle.pack_key(b, i + idx_offset, metric))
 
     @staticmethod
-    def finalize(x, table, keys, metric, ste, want_sq_err):
-        best, idx = vq_oracle.unpack_key(keys.numpy(), metric)
-        q = table[torch.from_numpy(idx)]
+    def finalize(x, table, keys, metric, ste, want_sq_err, out=None, idx=None, best=None):
+        if keys.dim() == 2:  # candidate planes: the winner is the MIN
+            keys = keys.amin(dim=0)
+        b, i = vq_oracle.unpack_key(keys.numpy(), metric)
+        q = table[torch.from_numpy(i)]
         sq = ((q - x).double() ** 2).sum().reshape(1) if want_sq_err else None
-        out = x + (q - x) if ste else q
-        return out, torch.from_numpy(idx), torch.from_numpy(best.copy()), sq
+        res = x + (q - x) if ste else q
+        it, bt = torch.from_numpy(i), torch.from_numpy(b.copy())
+        if out is not None:
+            out.copy_(res)
+            idx.copy_(it)
+            best.copy_(bt)
+            return out, idx, best, sq
+        return res, it, bt, sq
 
 
 def load_golden(name: str):

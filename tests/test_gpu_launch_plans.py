@@ -65,3 +65,35 @@ def test_module_forward_with_planned_launches_matches_scalar_search():
         assert torch.equal(idx.reshape(-1), ref["idx"].reshape(-1))
         qq = q if channel_last else q.permute(0, 2, 1)
         assert torch.equal(qq.reshape(-1, 256), ref["out"].reshape(-1, 256))
+
+
+@pytest.mark.parametrize("H,M,K,D,metric", [(1, 300, 4096, 128, 0), (1, 8192, 8192, 512, 0), (2, 500, 2048, 64, 1),
+                                            (1, 65536, 1024, 256, 0), (1, 200, 300, 700, 0)])
+def test_key_planes_need_no_init_and_no_atomics(H, M, K, D, metric):
+    """vq_search_key_planes_f32: a K split stores plane by plane (P = vq_key_planes > 1 when few rows would leave the chip
+    empty); the MIN over the planes -- taken by vq_finalize_key_planes_f32 on the fly -- is the one-plane atomic result, and
+    planes of several shards simply stack."""
+    from vector_quantization import native
+
+    native.load()
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    x = torch.randn((H, M, D), device=DEV, generator=g)
+    cb = torch.randn((H, K, D), device=DEV, generator=g)
+    ref = torch.empty((H, M), dtype=torch.int64, device=DEV)
+    native.keys_init(ref)
+    native.search_keys(x, cb, ref, metric=metric)
+    planes = native.search_key_planes(x, cb, metric=metric)
+    assert planes.dim() == 3 and tuple(planes.shape[1:]) == (H, M)
+    if M <= 8192 and D <= 512:
+        assert planes.shape[0] > 1, "few rows: K must have been split over workgroups"
+    assert torch.equal(planes.amin(dim=0), ref)
+    fin1 = native.finalize_keys(x, cb, ref, metric=metric)
+    finp = native.finalize_keys(x, cb, planes, metric=metric)
+    for k in ("out", "idx", "best"):
+        assert torch.equal(fin1[k], finp[k]), k
+    # two shards, planes stacked: the finalize's MIN over 2 P planes is the full search
+    half = K // 2
+    p0 = native.search_key_planes(x, cb[:, :half].contiguous(), metric=metric, idx_offset=0)
+    p1 = native.search_key_planes(x, cb[:, half:].contiguous(), metric=metric, idx_offset=half)
+    fin2 = native.finalize_keys(x, cb, torch.cat([p0, p1], dim=0), metric=metric)
+    assert torch.equal(fin2["idx"], fin1["idx"]) and torch.equal(fin2["out"], fin1["out"])

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, metric_dot, gather, K, D, M, out_dir, reduction="all_reduce"):
+def _worker(rank, world, port, metric_dot, gather, K, D, M, out_dir, reduction="all_reduce", overlap_rows=None):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,8 +41,12 @@ def _worker(rank, world, port, metric_dot, gather, K, D, M, out_dir, reduction="
     kl = K // world
     shard = full[rank * kl:(rank + 1) * kl]
     s = ShardedCodebookSearch(shard, use_cosine_sim=metric_dot, full_codebook=full if gather != "owner" else None,
-                              ops=OracleShardOps, reduction=reduction)
-    out, idx, best, sq = s(x, want_sq_err=True)
+                              ops=OracleShardOps, reduction=reduction, overlap_rows=overlap_rows)
+    out, idx, best, sq = s(x, want_sq_err=overlap_rows is None)
+    if overlap_rows is not None:  # the two-halves path reports no squared error; also exercise the phase profile
+        sq = ((out - x).double() ** 2).sum().reshape(1)
+        ph = s.profile_phases(x, steps=1)
+        assert set(ph) >= {"search_ms", "exchange_ms", "finalize_ms", "host_us", "step_ms", "key_planes"}
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), out=out.numpy(), idx=idx.numpy(),
              best=(best.numpy() if best is not None else np.zeros(1, np.float32)), sq=sq.numpy())
     dist.barrier()
@@ -73,6 +77,25 @@ def test_sharded_equals_full(tmp_path, oracle, world, metric_dot, gather, reduct
         np.testing.assert_allclose(z["sq"][0], ((full[ref_idx] - x).astype(np.float64) ** 2).sum(), rtol=1e-9)
     if gather == "dup":  # duplicated second half lives on the upper ranks: ties must go to the lower ranks
         assert ref_idx.max() < K // 2
+
+
+@pytest.mark.parametrize("world,reduction", [(2, "all_gather"), (3, "all_reduce")])
+def test_overlapped_halves_equal_full(tmp_path, oracle, world, reduction):
+    """Large batches are cut in two halves so that the exchange of the first runs under the search of the second
+    (asynchronous collectives): same result as one piece, any cut."""
+    from gen import make_codebook, make_x
+
+    K, D, M = 384, 32, 777
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, False, "replicated", K, D, M, str(tmp_path), reduction, 300), nprocs=world, join=True)
+    full = make_codebook(1, K, D, "S")[0].numpy()
+    x = make_x((M, D), "S").numpy()
+    ref_idx, ref_best = oracle.nearest(x, full, oracle.EUCLID)
+    for r in range(world):
+        z = np.load(tmp_path / f"r{r}.npz")
+        np.testing.assert_array_equal(z["idx"], ref_idx)
+        np.testing.assert_array_equal(z["out"], full[ref_idx])
+        assert np.array_equal(z["best"].view(np.uint32), ref_best.view(np.uint32))
 
 
 def _worker_local_rows(rank, world, port, K, D, m_local, out_dir):

@@ -450,7 +450,10 @@ int check_common(const vq_args *a) {
 }
 
 // Workspace layout: [keys: H*M int64][loss partials: floats]
-long long ws_keys_bytes(int H, long long M) { return ((long long)H * M * 8 + 255) / 256 * 256; }
+// one plane of keys + room for the planes of a K split (few rows: <= 512 x 256 extra keys; a planned split of a mid-size row
+// count: a few planes) -- when the planes do not fit, the splits fall back to ONE plane combined with atomic MIN
+constexpr long long kKeyPlanesExtraBytes = 8ll << 20;
+long long ws_keys_bytes(int H, long long M) { return ((long long)H * M * 8 + 255) / 256 * 256 + kKeyPlanesExtraBytes; }
 // loss partials: one float per wave, stage and 32 rows (16 rows for the wave-pair kernel of 256 < D <= 512)
 long long ws_loss_floats(int H, long long M, int Q) { return (long long)H * ((M + 15) / 16 + 16) * Q + (long long)H * 8192 + 64; }
 
@@ -479,10 +482,12 @@ void fill_search_params(SearchParams &p, const vq_args *a) {
                  (!a->cb || (a->cb_hs % 4 == 0 && a->cb_qs % 4 == 0 && aligned16(a->cb)))) ? 1 : 0;
 }
 
-int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipStream_t s, int *nparts_out) {
+int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipStream_t s, int *nparts_out, int key_planes = 1) {
     FinalizeParams f;
     memset(&f, 0, sizeof(f));
     f.keys = keys;
+    f.nparts = key_planes;
+    f.part_stride = (long long)a->H * a->M;
     f.x = a->x; f.x_rs = a->x_rs; f.x_hs = a->x_hs;
     f.cb = a->cb; f.cb_hs = a->cb_hs;
     f.out = a->out; f.out_rs = a->out_rs; f.out_hs = a->out_hs;
@@ -701,11 +706,55 @@ int run_wide(const vq_args *a, long long idx_offset, long long *keys, float *sim
     return 0;
 }
 
-int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hipStream_t s, int planned_splits = 0) {
-    const int DP = padded_dim(a->D);
-    if (DP == 0 && !(a->flags & VQ_F_FORCE_SIMPLE)) return run_wide(a, idx_offset, keys, nullptr, 0, 0, s);
-    const bool simple = (a->flags & VQ_F_FORCE_SIMPLE) || DP == 0;
-    if (simple) {
+// How a keys-mode search of `a` is launched on this device: workgroup size and the number of K splits (= key planes when the
+// splits store into planes of their own instead of combining with atomic MIN).
+struct KeysPlan {
+    int DP, waves, splits, tiles_per_split;
+    bool mfma;  // false: the one-thread-per-row kernel / the sliced sweep of wide rows (one plane, atomic MIN)
+};
+
+KeysPlan plan_keys(const vq_args *a, int planned_splits) {
+    KeysPlan k;
+    k.DP = padded_dim(a->D);
+    k.mfma = k.DP != 0 && !(a->flags & VQ_F_FORCE_SIMPLE);
+    k.waves = 8;
+    k.splits = 1;
+    k.tiles_per_split = 1;
+    if (!k.mfma) return k;
+    const DevInfo &di = dev_info();
+    const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+    const int tc = kTileCodes * sub_tiles(k.DP);
+    const int ntiles = (a->K + tc - 1) / tc;
+    k.waves = (k.DP == 512) ? 4 : 8;
+    long long wgs = (long long)a->H * ((a->M + 32 * k.waves - 1) / (32 * k.waves));
+    if (k.waves == 8 && wgs < cus && planned_splits == 0) {
+        k.waves = 4;
+        wgs = (long long)a->H * ((a->M + 127) / 128);
+    }
+    // K is split until the chip is full: two 4-wave workgroups fit a CU at Dp <= 256, one (LDS) at Dp = 512 -- splitting
+    // further only repeats the prologue and, in the wave-pair kernel, the extra pipeline step
+    const long long fill = (long long)cus * (k.DP == 512 ? 1 : 2);
+    int splits = 1;
+    if (planned_splits > 0) {
+        splits = planned_splits < ntiles ? planned_splits : ntiles;  // (plan_k_split: full-size workgroups, S splits)
+    } else if (wgs < fill) {
+        splits = (int)((fill + wgs - 1) / wgs);
+        if (splits > ntiles) splits = ntiles;
+        if (splits < 1) splits = 1;
+    }
+    k.tiles_per_split = (ntiles + splits - 1) / splits;
+    k.splits = (ntiles + k.tiles_per_split - 1) / k.tiles_per_split;  // every split owns at least one tile
+    return k;
+}
+
+// `part_stride` > 0: K split z stores its keys into plane z (planes part_stride keys apart, plan_keys(..).splits of them,
+// nothing to initialise); 0: all splits combine into ONE plane with atomic MIN (the caller initialised it).
+int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hipStream_t s, int planned_splits = 0,
+                    long long part_stride = 0) {
+    const KeysPlan kp = plan_keys(a, planned_splits);
+    if (!kp.mfma && part_stride > 0) return fail(VQ_E_UNSUPPORTED, "vq: key planes need the MFMA kernel (D <= 512)");
+    if (kp.DP == 0 && !(a->flags & VQ_F_FORCE_SIMPLE)) return run_wide(a, idx_offset, keys, nullptr, 0, 0, s);
+    if (!kp.mfma) {
         if (!a->cb) return fail(VQ_E_BADARG, "vq: natural codebook required for the scalar kernel");
         dim3 grid((unsigned)((a->M + 63) / 64), (unsigned)a->H);
         if (a->metric == VQ_METRIC_EUCLID)
@@ -723,34 +772,15 @@ int run_search_keys(const vq_args *a, long long idx_offset, long long *keys, hip
         return fail(VQ_E_UNSUPPORTED, "vq: packed codebook image >= 2 GiB (shard the codebook)");
     SearchParams p;
     fill_search_params(p, a);
-    p.mode = kModeKeys;
+    p.mode = part_stride > 0 ? kModeKeyParts : kModeKeys;
+    p.key_zs = part_stride;
     p.keys = keys;
     p.idx_offset = idx_offset;
     p.Q = 1;
     p.out = nullptr;
     p.loss_part = nullptr;
-    const DevInfo &di = dev_info();
-    const int cus = di.ok && di.cus > 0 ? di.cus : 256;
-    int waves = (DP == 512) ? 4 : 8;
-    long long wgs = (long long)a->H * ((a->M + 32 * waves - 1) / (32 * waves));
-    if (waves == 8 && wgs < cus && planned_splits == 0) {
-        waves = 4;
-        wgs = (long long)a->H * ((a->M + 127) / 128);
-    }
-    // K is split until the chip is full: two 4-wave workgroups fit a CU at Dp <= 256, one (LDS) at Dp = 512 -- splitting
-    // further only repeats the prologue and, in the wave-pair kernel, the extra pipeline step
-    const long long fill = (long long)cus * (DP == 512 ? 1 : 2);
-    int splits = 1;
-    if (planned_splits > 0) {
-        splits = planned_splits < p.ntiles ? planned_splits : p.ntiles;  // (plan_k_split: full-size workgroups, S splits)
-    } else if (wgs < fill) {
-        splits = (int)((fill + wgs - 1) / wgs);
-        if (splits > p.ntiles) splits = p.ntiles;
-        if (splits < 1) splits = 1;
-    }
-    p.tiles_per_split = (p.ntiles + splits - 1) / splits;
-    splits = (p.ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
-    return launch_search(DP, waves, p, a->H, splits, a->metric, s);
+    p.tiles_per_split = kp.tiles_per_split;
+    return launch_search(kp.DP, kp.waves, p, a->H, kp.splits, a->metric, s);
 }
 
 }  // namespace
@@ -849,9 +879,36 @@ int vq_search_keys_f32(const vq_args *a, int64_t idx_offset, int64_t *keys, void
     return run_search_keys(a, idx_offset, (long long *)keys, (hipStream_t)stream);
 }
 
-int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream) {
+int vq_key_planes(const vq_args *a) {
+    if (check_common(a) || a->Q != 1 || a->M == 0) return 1;
+    const KeysPlan kp = plan_keys(a, 0);
+    return kp.mfma ? kp.splits : 1;
+}
+
+int vq_search_key_planes_f32(const vq_args *a, int64_t idx_offset, int64_t *keys, void *stream) {
     int rc = check_common(a);
     if (rc) return rc;
+    if (a->Q != 1) return fail(VQ_E_BADARG, "vq_search_key_planes: Q must be 1");
+    if (!keys) return fail(VQ_E_BADARG, "vq_search_key_planes: keys is null");
+    if (idx_offset < 0 || idx_offset + a->K > 0xFFFFFFFFll) return fail(VQ_E_BADARG, "vq_search_key_planes: index range");
+    if (a->M == 0) return 0;
+    const KeysPlan kp = plan_keys(a, 0);
+    if (!kp.mfma) {  // scalar kernel / wide rows: one plane, combined with atomic MIN
+        rc = vq_keys_init(keys, (int64_t)a->H * a->M, stream);
+        if (rc) return rc;
+        return run_search_keys(a, idx_offset, (long long *)keys, (hipStream_t)stream);
+    }
+    return run_search_keys(a, idx_offset, (long long *)keys, (hipStream_t)stream, 0, (long long)a->H * a->M);
+}
+
+int vq_finalize_key_planes_f32(const vq_args *a, const int64_t *keys, int n_planes, void *stream);
+
+int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream) { return vq_finalize_key_planes_f32(a, keys, 1, stream); }
+
+int vq_finalize_key_planes_f32(const vq_args *a, const int64_t *keys, int n_planes, void *stream) {
+    int rc = check_common(a);
+    if (rc) return rc;
+    if (n_planes < 1) return fail(VQ_E_BADARG, "vq_finalize_keys: n_planes must be >= 1");
     if (a->Q != 1) return fail(VQ_E_BADARG, "vq_finalize_keys: Q must be 1");
     if (!keys || !a->cb) return fail(VQ_E_BADARG, "vq_finalize_keys: keys / cb is null");
     if (a->M == 0) {
@@ -866,7 +923,7 @@ int vq_finalize_keys_f32(const vq_args *a, const int64_t *keys, void *stream) {
         loss_part = (float *)((char *)a->workspace + ws_keys_bytes(a->H, a->M));
     }
     int nparts = 0;
-    rc = run_finalize(a, (const long long *)keys, loss_part, s, &nparts);
+    rc = run_finalize(a, (const long long *)keys, loss_part, s, &nparts, n_planes);
     if (rc) return rc;
     if (a->sq_err) {
         hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_part, (long long)nparts, 1, a->sq_err);
@@ -975,12 +1032,21 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     if (a->Q != 1) return fail(VQ_E_UNSUPPORTED, "vq_quantize: residual stages need the MFMA kernel (D <= 512)");
     if ((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err)
         return fail(VQ_E_UNSUPPORTED, "vq_quantize: per-head squared errors need the MFMA kernel (D <= 512)");
-    rc = vq_keys_init((int64_t *)keys, (int64_t)a->H * a->M, stream);
-    if (rc) return rc;
-    rc = run_search_keys(a, 0, keys, s, fused ? 0 : planned_splits);
+    // K split over workgroups: every split stores its winners into a key plane of its own and the finalize takes the MIN
+    // over the planes (no init launch, no atomics); if the planes do not fit the workspace, one plane + atomic MIN
+    const int sp = fused ? 0 : planned_splits;
+    const KeysPlan kp = plan_keys(a, sp);
+    int planes = 1;
+    if (kp.mfma && (long long)kp.splits * a->H * a->M * 8 <= ws_keys_bytes(a->H, a->M)) planes = kp.splits;
+    if (!kp.mfma || planes != kp.splits) {
+        rc = vq_keys_init((int64_t *)keys, (int64_t)a->H * a->M, stream);
+        if (rc) return rc;
+        planes = 1;
+    }
+    rc = run_search_keys(a, 0, keys, s, sp, kp.mfma && planes == kp.splits ? (long long)a->H * a->M : 0);
     if (rc) return rc;
     int nparts = 0;
-    rc = run_finalize(a, keys, a->sq_err ? loss_part : nullptr, s, &nparts);
+    rc = run_finalize(a, keys, a->sq_err ? loss_part : nullptr, s, &nparts, planes);
     if (rc) return rc;
     if (a->sq_err) {
         hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_part, (long long)nparts, 1, a->sq_err, acc);

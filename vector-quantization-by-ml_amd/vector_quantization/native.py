@@ -6,6 +6,7 @@ device, every entry point raises.  PyTorch is used only for device memory and th
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
 import threading
 
@@ -113,6 +114,12 @@ def load():
         lib.vq_search_keys_f32.restype = ctypes.c_int
         lib.vq_finalize_keys_f32.argtypes = [ap, _vp, _vp]
         lib.vq_finalize_keys_f32.restype = ctypes.c_int
+        lib.vq_key_planes.argtypes = [ap]
+        lib.vq_key_planes.restype = ctypes.c_int
+        lib.vq_search_key_planes_f32.argtypes = [ap, _i64, _vp, _vp]
+        lib.vq_search_key_planes_f32.restype = ctypes.c_int
+        lib.vq_finalize_key_planes_f32.argtypes = [ap, _vp, ctypes.c_int, _vp]
+        lib.vq_finalize_key_planes_f32.restype = ctypes.c_int
         lib.vq_ema_accumulate_f32.argtypes = [_vp, _i64, _i64, _vp, _i64, _i64, _vp, ctypes.c_int, _i64, ctypes.c_int,
                                               ctypes.c_int, _vp, _vp, _vp]
         lib.vq_ema_accumulate_f32.restype = ctypes.c_int
@@ -148,7 +155,7 @@ EXPORTED_SYMBOLS = (
     "vq_device_info", "vq_ema_accumulate_f32", "vq_ema_update_f32", "vq_similarities_f32", "vq_softmax_stats_f32",
     "vq_ce_backward_f32", "vq_quantize_lse_f32",
     "vq_quantize_backward_f32", "vq_ema_accumulate_residual_f32", "vq_max_fused_stages", "vq_ema_accumulate_det_f32",
-    "vq_ema_det_workspace_bytes",
+    "vq_ema_det_workspace_bytes", "vq_key_planes", "vq_search_key_planes_f32", "vq_finalize_key_planes_f32",
 )
 
 
@@ -184,6 +191,7 @@ def max_fused_stages(D: int, want_sq_err: bool) -> int:
     return int(load().vq_max_fused_stages(int(D), 1 if want_sq_err else 0))
 
 
+@functools.lru_cache(maxsize=256)
 def packed_floats(K: int, D: int) -> int:
     return int(load().vq_packed_floats(K, D))
 
@@ -339,15 +347,54 @@ def search_keys(x: torch.Tensor, cb: torch.Tensor, keys: torch.Tensor, *, metric
                "vq_search_keys_f32")
 
 
+def search_key_planes(x: torch.Tensor, cb: torch.Tensor, *, metric: int = EUCLID, idx_offset: int = 0,
+                      packed: torch.Tensor | None = None, flags: int = 0) -> torch.Tensor:
+    """Shard-local search without init launch or atomics: -> keys [P, H, M] int64, P = the K splits the library chose for
+    this shape (vq_key_planes); the winner of a row is the MIN over the planes (and over the other shards' planes)."""
+    _require_gpu(x, cb)
+    assert x.dim() == 3 and cb.dim() == 3 and cb.is_contiguous()
+    H, M, D = x.shape
+    _, K, _ = cb.shape
+    if packed is None:
+        packed = pack_codebooks(cb, metric)
+    _check_packed(packed, H, K, D, x.device)
+    x_rs, x_hs = _row_strides(x)
+    a = VqArgs()
+    a.H, a.Q, a.M, a.K, a.D, a.metric, a.flags = H, 1, M, K, D, metric, flags
+    a.x, a.x_rs, a.x_hs = x.data_ptr(), x_rs, x_hs
+    a.cb, a.cb_hs, a.cb_qs = cb.data_ptr(), K * D, 0
+    a.packed, a.pk_hs, a.pk_qs = packed.data_ptr(), packed.shape[-1], 0
+    if D > 512:
+        ws = _workspace(H, M, 1, x.device, K, D)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8
+    with torch.cuda.device(x.device):
+        planes = int(load().vq_key_planes(ctypes.byref(a)))
+        keys = torch.empty((planes, H, M), dtype=torch.int64, device=x.device)
+        _check(load().vq_search_key_planes_f32(ctypes.byref(a), idx_offset, keys.data_ptr(), _stream_ptr(x.device)),
+               "vq_search_key_planes_f32")
+    return keys
+
+
 def finalize_keys(x: torch.Tensor, cb_full: torch.Tensor, keys: torch.Tensor, *, metric: int = EUCLID, ste: bool = False,
-                  want_sq_err: bool = False, out: torch.Tensor | None = None, want_out: bool = True):
-    """Decode reduced keys and gather from the FULL natural codebook cb_full [H, K_total, D]."""
+                  want_sq_err: bool = False, out: torch.Tensor | None = None, want_out: bool = True,
+                  idx: torch.Tensor | None = None, best: torch.Tensor | None = None):
+    """Decode reduced keys and gather from the FULL natural codebook cb_full [H, K_total, D].  ``keys`` [H, M], or candidate
+    planes [P, H, M] whose MIN is taken on the fly (K splits x shards)."""
     _require_gpu(x, cb_full, keys)
     H, M, D = x.shape
+    planes = 1
+    if keys.dim() == 3:
+        planes = keys.shape[0]
+        assert tuple(keys.shape[1:]) == (H, M)
+    assert keys.dtype == torch.int64 and keys.is_contiguous()
     K = cb_full.shape[1]
     dev = x.device
-    idx = torch.empty((H, M), dtype=torch.int64, device=dev)
-    best = torch.empty((H, M), dtype=torch.float32, device=dev)
+    if idx is None:  # (idx / best may be [H, M] views of larger buffers: same strides, last dim contiguous)
+        idx = torch.empty((H, M), dtype=torch.int64, device=dev)
+    if best is None:
+        best = torch.empty_strided((H, M), idx.stride(), dtype=torch.float32, device=dev)
+    assert tuple(idx.shape) == (H, M) and tuple(best.shape) == (H, M) and idx.stride() == best.stride()
+    assert idx.dtype == torch.int64 and best.dtype == torch.float32
     if want_out and out is None:
         out = torch.empty((H, M, D), dtype=torch.float32, device=dev)
     sq_err = torch.empty((1,), dtype=torch.float64, device=dev) if want_sq_err else None
@@ -361,12 +408,13 @@ def finalize_keys(x: torch.Tensor, cb_full: torch.Tensor, keys: torch.Tensor, *,
     if out is not None:
         o_rs, o_hs = _row_strides(out)
         a.out, a.out_rs, a.out_hs = out.data_ptr(), o_rs, o_hs
-    a.idx, a.idx_rs, a.idx_hs, a.idx_qs = idx.data_ptr(), 1, M, 0
+    a.idx, a.idx_rs, a.idx_hs, a.idx_qs = idx.data_ptr(), int(idx.stride(1)) if M > 1 else 1, int(idx.stride(0)), 0
     a.best = best.data_ptr()
     a.sq_err = sq_err.data_ptr() if sq_err is not None else None
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 8
     with torch.cuda.device(dev):
-        _check(load().vq_finalize_keys_f32(ctypes.byref(a), keys.data_ptr(), _stream_ptr(dev)), "vq_finalize_keys_f32")
+        _check(load().vq_finalize_key_planes_f32(ctypes.byref(a), keys.data_ptr(), planes, _stream_ptr(dev)),
+               "vq_finalize_key_planes_f32")
     return dict(out=out, idx=idx, best=best, sq_err=sq_err)
 
 

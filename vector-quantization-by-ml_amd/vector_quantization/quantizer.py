@@ -201,14 +201,17 @@ class VectorQuantize(nn.Module):
         return self.project_out(codes)
 
     # ------------------------------------------------------------------ codebook sharded over a process group
-    def _reduce_keys(self, keys):
-        """Element-wise MIN of the packed keys over the shard group (identical result on every rank)."""
+    def _reduce_keys(self, planes):
+        """This rank's candidate planes [P, h, M] of packed keys -> the candidate planes of the whole codebook (identical on
+        every rank): all G * P planes after the one-hop all-gather, or P planes reduced with MIN by the all-reduce.  The
+        finalize takes the MIN over whatever planes it is handed."""
+        planes = planes.contiguous()
         if self.shard_reduction == "all_gather":
-            every = torch.empty((self.shard_world * keys.numel(),), dtype=torch.int64, device=keys.device)
-            dist.all_gather_into_tensor(every, keys.reshape(-1), group=self.shard_group)
-            return every.view(self.shard_world, *keys.shape).amin(dim=0)
-        dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=self.shard_group)
-        return keys
+            every = torch.empty((self.shard_world * planes.shape[0], *planes.shape[1:]), dtype=torch.int64, device=planes.device)
+            dist.all_gather_into_tensor(every.view(-1), planes.view(-1), group=self.shard_group)
+            return every
+        dist.all_reduce(planes, op=dist.ReduceOp.MIN, group=self.shard_group)
+        return planes
 
     def gather_table(self):
         """The full natural codebook [h, K, D], all-gathered from the shards and cached until this rank's shard changes
@@ -231,12 +234,13 @@ class VectorQuantize(nn.Module):
         cb, backend = self._codebook, search.get_backend()
         k_local = cb.codebook_size
         x = flat if flat.dtype == torch.float32 else flat.float()
-        keys = backend.shard_keys(x, cb.embeddings.detach(), metric=cb.metric, idx_offset=self.shard_rank * k_local,
-                                  packed=cb.packed_codes())
-        keys = self._reduce_keys(keys)
+        planes = backend.shard_keys(x, cb.embeddings.detach(), metric=cb.metric, idx_offset=self.shard_rank * k_local,
+                                    packed=cb.packed_codes())
+        planes = self._reduce_keys(planes if planes.dim() == 3 else planes[None])
         if self.shard_gather == "replicated":
-            quant, idx = backend.finalize_keys(x, self.gather_table(), keys, metric=cb.metric)
+            quant, idx = backend.finalize_keys(x, self.gather_table(), planes, metric=cb.metric)
         else:
+            keys = planes[0] if planes.shape[0] == 1 else planes.amin(dim=0)
             idx = keys & 0xFFFFFFFF
             local = idx - self.shard_rank * k_local
             mine = (local >= 0) & (local < k_local)

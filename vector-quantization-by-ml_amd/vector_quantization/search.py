@@ -84,17 +84,16 @@ class _NativeBackend:
 
     @staticmethod
     def shard_keys(x, cb, *, metric, idx_offset, packed=None):
-        """Search ONE SHARD of a codebook: x [H, M, D], cb [H, K_local, D] -> packed signed 64-bit keys [H, M]
-        ((order image of the winning value) << 32 | idx_offset + local index; vq_keys_init + vq_search_keys_f32).
-        The element-wise MIN of the shards' keys is the whole codebook's winner, lowest index on ties."""
-        keys = torch.empty((x.shape[0], x.shape[1]), dtype=torch.int64, device=x.device)
-        native.keys_init(keys)
-        native.search_keys(x, cb, keys, metric=metric, idx_offset=idx_offset, packed=packed)
-        return keys
+        """Search ONE SHARD of a codebook: x [H, M, D], cb [H, K_local, D] -> packed signed 64-bit keys, candidate planes
+        [P, H, M] ((order image of the winning value) << 32 | idx_offset + local index; vq_search_key_planes_f32: one
+        launch, no init, no atomics -- P = the K splits that fill the chip for this shape).  The element-wise MIN over the
+        planes of all shards is the whole codebook's winner, lowest index on ties."""
+        return native.search_key_planes(x, cb, metric=metric, idx_offset=idx_offset, packed=packed)
 
     @staticmethod
     def finalize_keys(x, table, keys, *, metric):
-        """Reduced keys + a FULL natural table [H, K, D] -> (quantized rows [H, M, D], idx [H, M]) (vq_finalize_keys_f32)."""
+        """Keys [H, M] or candidate planes [C, H, M] (MIN taken on the fly) + a FULL natural table [H, K, D] ->
+        (quantized rows [H, M, D], idx [H, M]) (vq_finalize_key_planes_f32)."""
         r = native.finalize_keys(x, table, keys, metric=metric)
         return r["out"], r["idx"]
 
