@@ -43,9 +43,11 @@ extern "C" {
 
 /*
  * Packed codebook image (the layout the search kernel streams through LDS).  For one codebook of
- * K codes x D dims:  Kp = roundup(K, 32) rows of (Dp + 4) floats, Dp = padded dim chosen by the library
- * (32/64/128/256/512); inside each group of 8 dims the even dims come first, then the odd ones, values
- * pre-scaled by -2 (Euclid) or 1 (dot); float Dp of each row holds |c|^2 (d-ordered fmaf chain).
+ * K codes x D dims:  Kp rows of (Dp + 4) floats, Dp = padded dim chosen by the library (32/64/128/256/512) and Kp = K
+ * rounded up to the staged LDS tile (32 codes at Dp >= 256, else 256 / Dp * 32: 64 / 128 / 256 codes at Dp = 128 / 64 / 32);
+ * inside each group of 8 dims the even dims come first, then the odd ones, values pre-scaled by -2 (Euclid) or 1 (dot);
+ * float Dp of each row holds |c|^2 (d-ordered fmaf chain; +inf for the padding rows), float Dp + 1 holds 1.0, float
+ * Dp + 2 the same chain under either metric; the last 16 bytes of the image hold a "some code is non-finite" word.
  * D > 512: ceil(D / 256) such images back to back, one per 256-dim slice of the rows (the last one as wide as it needs).
  * Returns the number of floats ONE packed codebook occupies (including over-copy slack), 0 on bad args.
  */

@@ -27,7 +27,8 @@ def _rand(shape, seed):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
 
 
-@pytest.mark.parametrize("M,K,D,H", [(262144, 1024, 256, 1), (262144, 8192, 256, 1), (65536, 8192, 64, 8)])
+@pytest.mark.parametrize("M,K,D,H", [(262144, 1024, 256, 1), (262144, 8192, 256, 1), (65536, 8192, 64, 8),
+                                     (65536, 8192, 512, 8)])  # cfg2, north-star shape, cfg3a, cfg3b at BASELINE size
 def test_full_size_sample_idempotence_identity(oracle, M, K, D, H):
     native = _native()
     x = _rand((H, M, D), 1234).to(DEV)
@@ -36,7 +37,11 @@ def test_full_size_sample_idempotence_identity(oracle, M, K, D, H):
     idx, best, out = r["idx"][..., 0], r["best"][..., 0], r["out"]
     # (a) oracle on a sample of rows
     g = torch.Generator().manual_seed(7)
-    rows = torch.randperm(M, generator=g)[:2048]
+    rows = torch.randperm(M, generator=g)[:(2048 if D <= 256 else 768)]
+    if D > 256:  # cfg3b (fused multi-head wave-pair launch): also every row of a slice against the one-thread-per-row kernel
+        sl = native.quantize(x[:, 1000:3048], cb, flags=native.F_FORCE_SIMPLE)
+        assert torch.equal(sl["idx"][..., 0], idx[:, 1000:3048])
+        assert torch.equal(sl["best"][..., 0].view(torch.int32), best[:, 1000:3048].view(torch.int32))
     for h in range(H):
         ri, rb = oracle.nearest(x[h, rows].cpu().numpy(), cb[h, 0].cpu().numpy(), oracle.EUCLID)
         np.testing.assert_array_equal(idx[h, rows].cpu().numpy(), ri)
@@ -139,7 +144,7 @@ def test_modules_accept_empty_half_precision_and_noncontiguous(oracle):
     assert q.dtype == torch.float32
 
 
-def test_large_dim_uses_scalar_kernel(oracle):
+def test_rows_wider_than_512_dims_take_the_sliced_sweep(oracle):
     native = _native()
     x = _rand((1, 100, 700), 1)
     cb = _rand((1, 1, 50, 700), 2)

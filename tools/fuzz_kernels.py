@@ -1,9 +1,11 @@
 """Randomised cross-check of the MFMA kernels (dev tool, GPU box):  python tools/fuzz_kernels.py [seconds] [seed]
+(tests/test_gpu_fuzz.py runs `run()` with a fixed seed and a bounded budget inside the -m gpu suite).
 
-Single stage: random (H, M, K, D, metric, ste) -> the launcher's choice (one-block, persistent, wave-pair, split-K) must equal
-the scalar kernel bit for bit (indices, winning values, outputs) -- both follow the oracle's k-ordered chain.
+Single stage: random (H, M, K, D, metric, ste) -> the launcher's choice (one-block, persistent, wave-pair, split-K, main + tail)
+must equal the scalar kernel bit for bit (indices, winning values, outputs) -- both follow the oracle's k-ordered chain.
 Rows wider than 512 dims (sliced sweep, chains carried through the workspace): the same check, D up to 2100.
-Residual stacks: random (Q, M, K, D, train) against the CPU oracle (indices and outputs exact)."""
+Residual stacks: random (Q, M, K, D, train) against the CPU oracle (indices and outputs exact).
+One configuration in five is poisoned with NaN / +-inf entries in rows and / or codes (ATen's argmax rule: the first NaN wins)."""
 import os
 import sys
 import time
@@ -12,72 +14,108 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vector-quantization-by-ml_amd")]
 import numpy as np
 import torch
-from oracle import vq_oracle
-from vector_quantization import native
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-rng = np.random.default_rng(seed)
-dev = torch.device("cuda:0")
-native.load()
-t_end = time.time() + budget
-n1 = n2 = n3 = 0
-while time.time() < t_end:
-    pick = rng.random()
-    if pick < 0.7:
-        wide = pick < 0.2
-        if wide:
-            D = int(rng.integers(513, 2100))
-            K = int(rng.choice([1, 7, 33, 100, 256, 1000, 1024, 1100, 4100, 5000, 8200]))
-            H = int(rng.choice([1, 1, 2, 9]))
-            M = max(1, min(int(rng.integers(1, 60000)), int(1.5e10 / (K * D)))) // H + 1  # the scalar witness is one thread per row
+
+def _same(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """bit-equal, NaN == NaN (a NaN's payload is not part of the contract)"""
+    an, bn = torch.isnan(a), torch.isnan(b)
+    return bool(torch.equal(an, bn)) and bool(torch.equal(torch.where(an, torch.zeros_like(a), a).view(torch.int32),
+                                                            torch.where(bn, torch.zeros_like(b), b).view(torch.int32)))
+
+
+def _poison(rng, t: torch.Tensor, n: int):
+    flat = t.view(-1, t.shape[-1])
+    for _ in range(n):
+        r, d = int(rng.integers(flat.shape[0])), int(rng.integers(flat.shape[1]))
+        flat[r, d] = [float("nan"), float("inf"), float("-inf")][int(rng.integers(3))]
+
+
+def run(budget: float = 60.0, seed: int = 0, verbose: bool = True):
+    from oracle import vq_oracle
+    from vector_quantization import native
+
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    native.load()
+    t_end = time.time() + budget
+    n1 = n2 = n3 = n4 = 0
+    while time.time() < t_end:
+        pick = rng.random()
+        poisoned = rng.random() < 0.2
+        if pick < 0.7:
+            wide = pick < 0.2
+            if wide:
+                D = int(rng.integers(513, 2100))
+                K = int(rng.choice([1, 7, 33, 100, 256, 1000, 1024, 1100, 4100, 5000, 8200]))
+                H = int(rng.choice([1, 1, 2, 9]))
+                M = max(1, min(int(rng.integers(1, 60000)), int(1.5e10 / (K * D)))) // H + 1  # the scalar witness is one thread per row
+            else:
+                D = int(rng.choice([5, 24, 32, 48, 64, 100, 128, 132, 200, 256, 260, 300, 384, 500, 512]))
+                K = int(rng.choice([1, 7, 33, 100, 256, 1000, 1024, 1100, 2048, 3000, 4100]))
+                H = int(rng.choice([1, 1, 2, 3]))
+                big = rng.random() < 0.5
+                M = int(rng.integers(140000, 300000) // H) if big else int(rng.integers(1, 40000))
+                if D > 256 and big:
+                    M = int(rng.integers(33000, 70000) // H)
+            metric = int(rng.integers(0, 2))
+            ste = bool(rng.integers(0, 2))
+            g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+            grid = rng.random() < 0.25  # exact-grid values: forced ties
+            if grid:
+                x = torch.randint(-8, 9, (H, M, D), generator=g).float() / 4.0
+                cb = torch.randint(-8, 9, (H, 1, K, D), generator=g).float() / 4.0
+            else:
+                x = torch.randn((H, M, D), generator=g)
+                cb = torch.randn((H, 1, K, D), generator=g)
+            if poisoned:
+                _poison(rng, x, int(rng.integers(1, 6)))
+                if rng.random() < 0.4:
+                    _poison(rng, cb, int(rng.integers(1, 3)))
+            x, cb = x.to(dev), cb.to(dev)
+            a = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=ste)
+            s = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=ste, flags=native.F_FORCE_SIMPLE)
+            torch.cuda.synchronize()
+            ok = torch.equal(a["idx"], s["idx"]) and _same(a["best"], s["best"]) and _same(a["out"], s["out"])
+            if not ok:
+                bad = int((a["idx"] != s["idx"]).sum())
+                raise AssertionError(f"MISMATCH single: H={H} M={M} K={K} D={D} metric={metric} ste={ste} grid={grid} "
+                                     f"poisoned={poisoned}: {bad} indices differ")
+            n1 += 1
+            n3 += int(wide)
         else:
-            D = int(rng.choice([5, 24, 32, 48, 64, 100, 128, 132, 200, 256, 260, 300, 384, 500, 512]))
-            K = int(rng.choice([1, 7, 33, 100, 256, 1000, 1024, 1100, 2048, 3000, 4100]))
-            H = int(rng.choice([1, 1, 2, 3]))
-            big = rng.random() < 0.5
-            M = int(rng.integers(140000, 300000) // H) if big else int(rng.integers(1, 40000))
-            if D > 256 and big:
-                M = int(rng.integers(33000, 70000) // H)
-        metric = int(rng.integers(0, 2))
-        ste = bool(rng.integers(0, 2))
-        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
-        grid = rng.random() < 0.25  # exact-grid values: forced ties
-        if grid:
-            x = (torch.randint(-8, 9, (H, M, D), generator=g).float() / 4.0).to(dev)
-            cb = (torch.randint(-8, 9, (H, 1, K, D), generator=g).float() / 4.0).to(dev)
-        else:
-            x = torch.randn((H, M, D), generator=g).to(dev)
-            cb = torch.randn((H, 1, K, D), generator=g).to(dev)
-        a = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=ste)
-        s = native.quantize(x, cb, metric=metric, ste=ste, want_sq_err=ste, flags=native.F_FORCE_SIMPLE)
-        torch.cuda.synchronize()
-        ok = (torch.equal(a["idx"], s["idx"]) and torch.equal(a["best"].view(torch.int32), s["best"].view(torch.int32))
-              and torch.equal(a["out"], s["out"]))
-        if not ok:
-            bad = int((a["idx"] != s["idx"]).sum())
-            print(f"MISMATCH single: H={H} M={M} K={K} D={D} metric={metric} ste={ste} grid={grid}: {bad} indices differ", flush=True)
-            sys.exit(1)
-        n1 += 1
-        n3 += int(wide)
-    else:
-        D = int(rng.choice([24, 40, 64, 100, 128, 200, 256, 300, 512]))
-        K = int(rng.choice([7, 64, 100, 256, 1000]))
-        Q = int(rng.integers(2, 7))
-        M = int(rng.integers(1, 3000))
-        train = bool(rng.integers(0, 2))
-        g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
-        x = torch.randn((M, D), generator=g)
-        cbs = torch.stack([torch.randn((K, D), generator=g) * 2.0 ** (-i / 2.0) for i in range(Q)])
-        ref = vq_oracle.rvq_forward(x.numpy(), cbs.numpy(), 0, training=train)
-        r = native.quantize(x[None].to(dev), cbs[None].contiguous().to(dev), ste=train, want_sq_err=train)
-        torch.cuda.synchronize()
-        ok = (np.array_equal(r["idx"][0].cpu().numpy(), ref["idx"]) and np.array_equal(r["out"][0].cpu().numpy(), ref["out"])
-              and np.array_equal(r["best"][0].cpu().numpy().view(np.uint32), ref["best"].view(np.uint32)))
-        if not ok:
-            print(f"MISMATCH residual: Q={Q} M={M} K={K} D={D} train={train}", flush=True)
-            sys.exit(1)
-        n2 += 1
-    if (n1 + n2) % 20 == 0:
-        print(f"{n1} single-stage ({n3} of them wider than 512 dims), {n2} residual configurations agree", flush=True)
-print(f"done: {n1} single-stage ({n3} wider than 512 dims) and {n2} residual random configurations, all bit-exact", flush=True)
+            D = int(rng.choice([24, 40, 64, 100, 128, 200, 256, 300, 512]))
+            K = int(rng.choice([7, 64, 100, 256, 1000]))
+            Q = int(rng.integers(2, 7))
+            M = int(rng.integers(1, 3000))
+            train = bool(rng.integers(0, 2))
+            g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+            x = torch.randn((M, D), generator=g)
+            cbs = torch.stack([torch.randn((K, D), generator=g) * 2.0 ** (-i / 2.0) for i in range(Q)])
+            if poisoned:
+                _poison(rng, x, int(rng.integers(1, 6)))
+                if rng.random() < 0.4:
+                    _poison(rng, cbs, 1)
+            with np.errstate(invalid="ignore", over="ignore"):
+                ref = vq_oracle.rvq_forward(x.numpy(), cbs.numpy(), 0, training=train)
+            r = native.quantize(x[None].to(dev), cbs[None].contiguous().to(dev), ste=train, want_sq_err=train)
+            torch.cuda.synchronize()
+            ok = (np.array_equal(r["idx"][0].cpu().numpy(), ref["idx"]) and _same(r["out"][0].cpu(), torch.from_numpy(ref["out"]))
+                  and _same(r["best"][0].cpu(), torch.from_numpy(ref["best"])))
+            if not ok:
+                raise AssertionError(f"MISMATCH residual: Q={Q} M={M} K={K} D={D} train={train} poisoned={poisoned}")
+            n2 += 1
+        n4 += int(poisoned)
+        if verbose and (n1 + n2) % 20 == 0:
+            print(f"{n1} single-stage ({n3} of them wider than 512 dims), {n2} residual configurations agree ({n4} poisoned)", flush=True)
+    if verbose:
+        print(f"done: {n1} single-stage ({n3} wider than 512 dims) and {n2} residual random configurations "
+              f"({n4} with non-finite entries), all bit-exact", flush=True)
+    return dict(single=n1, wide=n3, residual=n2, poisoned=n4)
+
+
+if __name__ == "__main__":
+    try:
+        run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    except AssertionError as e:
+        print(e, flush=True)
+        sys.exit(1)

@@ -64,6 +64,7 @@ namespace {
 #include "vq_search.inc"
 #include "vq_search_pair.inc"
 #include "vq_search_persist.inc"
+#include "vq_search_resident.inc"
 #include "vq_similarity.inc"
 #if VQ_OWN(0)
 #include "vq_finalize_ema.inc"
@@ -213,6 +214,28 @@ int launch_persist_t(const SearchParams &p, int H, int cus, hipStream_t s) {
     return 0;
 }
 
+// small codebooks: the image stays in LDS, one 8-wave workgroup per CU, waves walk 32-row blocks (vq_search_resident.inc)
+template <int DP, int METRIC>
+int launch_resident_t(const SearchParams &p, int H, int cus, hipStream_t s) {
+    const size_t lds = ResGeo<DP>::lds_bytes(p.res_img_floats);
+    auto kern = vq_search_resident<DP, METRIC>;
+    static thread_local bool attr_done[kMaxDevices] = {};
+    if (int rc = allow_big_lds(kern, attr_done)) return rc;
+    const long long nwb = (p.M + 31) / 32;
+    long long gx = cus / H;
+    if (gx < 1) gx = 1;
+    if (gx > (nwb + 7) / 8) gx = (nwb + 7) / 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)H, 1), dim3(512), lds, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_search_resident launch");
+    return 0;
+}
+
+template <int DP>
+int launch_resident_m(const SearchParams &p, int H, int cus, int metric, hipStream_t s) {
+    return metric == VQ_METRIC_EUCLID ? launch_resident_t<DP, VQ_METRIC_EUCLID>(p, H, cus, s) : launch_resident_t<DP, VQ_METRIC_DOT>(p, H, cus, s);
+}
+
 template <int DP, int WAVES, int METRIC, int MODE>
 int launch_aux_t(const AuxParams &p, int H, hipStream_t s) {
     using G = Geo<DP, WAVES>;
@@ -259,6 +282,9 @@ int launch_ce_bwd_m(const CeBwdParams &p, int H, int metric, hipStream_t s) {
     return launch_ce_bwd_t<DP, VQ_METRIC_DOT>(p, H, s);
 }
 
+#ifndef VQ_EXP_RESIDENT_MIN_ROWS_PER_CU
+#define VQ_EXP_RESIDENT_MIN_ROWS_PER_CU 512  // rows per CU from which the resident-codebook kernel takes a small codebook
+#endif
 #ifndef VQ_EXP_WIDE_SLICE
 #define VQ_EXP_WIDE_SLICE 256
 #endif
@@ -295,6 +321,7 @@ int launch_wide_any(int wide, const SearchParams &p, int H, int splits, int metr
 namespace vqi {
 template <int DP> int part_search(int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s);
 template <int DP> int part_wide(int wide, const SearchParams &p, int H, int splits, int metric, hipStream_t s);
+template <int DP> int part_resident(const SearchParams &p, int H, int cus, int metric, hipStream_t s);
 template <int DP> int part_aux(const AuxParams &p, int H, int metric, int mode, hipStream_t s);
 template <int DP> int part_ce_bwd(const CeBwdParams &p, int H, int metric, hipStream_t s);
 int part_pair(const SearchParams &p, int H, int splits, int metric, hipStream_t s);
@@ -304,6 +331,9 @@ int part_persist(const SearchParams &p, int H, int cus, int metric, hipStream_t 
     template <> int part_wide<DP>(int wide, const SearchParams &p, int H, int splits, int metric, hipStream_t s);    \
     template <> int part_aux<DP>(const AuxParams &p, int H, int metric, int mode, hipStream_t s);                    \
     template <> int part_ce_bwd<DP>(const CeBwdParams &p, int H, int metric, hipStream_t s);
+template <> int part_resident<32>(const SearchParams &p, int H, int cus, int metric, hipStream_t s);
+template <> int part_resident<64>(const SearchParams &p, int H, int cus, int metric, hipStream_t s);
+template <> int part_resident<128>(const SearchParams &p, int H, int cus, int metric, hipStream_t s);
 VQ_DECLARE_PARTS(32)
 VQ_DECLARE_PARTS(64)
 VQ_DECLARE_PARTS(128)
@@ -318,13 +348,19 @@ VQ_DECLARE_PARTS(512)
     template <> int part_wide<DP>(int wide, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {    \
         return launch_wide_any<DP>(wide, p, H, splits, metric, s);                                                    \
     }
+#define VQ_DEFINE_RESIDENT_PART(DP) \
+    template <> int part_resident<DP>(const SearchParams &p, int H, int cus, int metric, hipStream_t s) { return launch_resident_m<DP>(p, H, cus, metric, s); }
 #if VQ_OWN(1)
 VQ_DEFINE_SEARCH_PART(32, 4)
 VQ_DEFINE_SEARCH_PART(64, 4)
+VQ_DEFINE_RESIDENT_PART(32)
+VQ_DEFINE_RESIDENT_PART(64)
 #endif
 #if VQ_OWN(2)
 VQ_DEFINE_SEARCH_PART(128, 4)
+VQ_DEFINE_RESIDENT_PART(128)
 #endif
+#undef VQ_DEFINE_RESIDENT_PART
 #if VQ_OWN(3)
 VQ_DEFINE_SEARCH_PART(256, 4)
 int part_persist(const SearchParams &p, int H, int cus, int metric, hipStream_t s) {
@@ -396,10 +432,35 @@ bool persist_selected(int DP, int waves, const SearchParams &p, int H, int split
     return nblk * H >= 2ll * cus;  // at least two blocks per resident workgroup
 }
 
+bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+// Small codebook, plain inference call (one stage, no straight-through / loss / LSE, aligned fp32 rows of D % 16 == 0 dims,
+// Dp <= 128) whose image fits the LDS beside the row slabs, and enough rows to give every wave slot of the chip a few 32-row
+// blocks: the resident-codebook kernel.  VQ_NO_RESIDENT=1 in the environment keeps the tile-streaming kernels (A/B measurements).
+int resident_image_for(const vq_args *a, int DP, bool lse, int cus) {
+    static const bool off = getenv("VQ_NO_RESIDENT") != nullptr;
+    if (off || DP == 0 || DP > 128 || a->Q != 1 || lse || a->sq_err || !a->out || !a->idx || !a->cb || !a->packed) return 0;
+    if (a->flags & (VQ_F_STE | VQ_F_FORCE_SIMPLE | VQ_F_FORCE_SPLIT | VQ_F_X_F16 | VQ_F_X_BF16)) return 0;
+    if (a->D % 16 || a->x_rs % 4 || a->x_hs % 4 || !aligned16(a->x)) return 0;
+    if (a->out_rs % 4 || a->out_hs % 4 || !aligned16(a->out) || a->cb_hs % 4 || !aligned16(a->cb)) return 0;
+    const int img = resident_image_floats(a->K, DP);
+    const size_t lds = ((size_t)img + 8 * 512) * 4 + 2 * 8 * 32 * 4;
+    if (lds > 160 * 1024) return 0;
+    if ((long long)a->H * a->M < (long long)VQ_EXP_RESIDENT_MIN_ROWS_PER_CU * cus) return 0;
+    return img;
+}
+
 int launch_search(int DP, int waves, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
     {
         const DevInfo &di = dev_info();
         const int cus = di.ok && di.cus > 0 ? di.cus : 256;
+        if (p.res_img_floats > 0 && splits == 1 && p.mode == kModeFused) {
+            switch (DP) {
+                case 32: return vqi::part_resident<32>(p, H, cus, metric, s);
+                case 64: return vqi::part_resident<64>(p, H, cus, metric, s);
+                case 128: return vqi::part_resident<128>(p, H, cus, metric, s);
+            }
+        }
         if (persist_selected(DP, waves, p, H, splits, cus))
             return vqi::part_persist(p, H, cus, metric, s);
     }
@@ -438,8 +499,6 @@ int launch_wide(int wide, int DP, const SearchParams &p, int H, int splits, int 
     }
     return fail(VQ_E_UNSUPPORTED, "vq_search: unsupported padded dim");
 }
-
-bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int check_common(const vq_args *a) {
     if (!a) return fail(VQ_E_BADARG, "vq: null args");
@@ -495,6 +554,8 @@ int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipS
     f.best = a->best;
     f.loss_part = loss_part;
     f.M = a->M; f.D = a->D; f.metric = a->metric; f.ste = (a->flags & VQ_F_STE) ? 1 : 0;
+    f.vec = (a->D % 4 == 0 && a->cb_hs % 4 == 0 && aligned16(a->cb) && (!a->out || (a->out_rs % 4 == 0 && a->out_hs % 4 == 0 && aligned16(a->out))) &&
+             (!(f.ste || loss_part) || (a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x)))) ? 1 : 0;
     long long blocks = (a->M + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
@@ -961,7 +1022,8 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     const int cus = di.ok && di.cus > 0 ? di.cus : 256;
 
     const int acc = (a->flags & kFlagAccumulateSqErr) ? 1 : 0;  // (internal: second call of a two-call plan adds its sum)
-    if (!simple && a->Q == 1 && !lse && !acc && !((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err) &&
+    const int res_img = (simple || acc) ? 0 : resident_image_for(a, DP, lse != nullptr, cus);
+    if (!res_img && !simple && a->Q == 1 && !lse && !acc && !((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err) &&
         !(a->flags & (VQ_F_FORCE_SPLIT | VQ_F_X_F16 | VQ_F_X_BF16))) {
         const long long m1 = plan_main_tail(DP, a->H, a->M, a->K, a->D, cus);
         if (m1 > 0 && m1 < a->M) {  // whole rounds fused, then the remainder as its own (K-split) call
@@ -1000,6 +1062,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
             planned_splits = plan_k_split(DP, a->H, a->M, a->K, a->D, cus);  // grid quantisation (see plan_k_split)
             if (planned_splits > 1) fused = false;
         }
+        if (res_img) fused = true;  // small codebook resident in LDS: 32-row granularity, no plan needed
         if (lse) fused = true;  // the log-sum-exp needs every code of a row in one workgroup
         if ((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err) fused = true;  // per-head partial sums exist on this path only
     }
@@ -1013,6 +1076,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         p.mode = kModeFused;
         p.loss_part = a->sq_err ? loss_part : nullptr;
         p.lse = lse;
+        p.res_img_floats = res_img;
         rc = launch_search(DP, waves, p, a->H, 1, a->metric, s);
         if (rc) return rc;
         if (a->sq_err) {
