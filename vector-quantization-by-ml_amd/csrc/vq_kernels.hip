@@ -217,7 +217,7 @@ int launch_persist_t(const SearchParams &p, int H, int cus, hipStream_t s) {
 // small codebooks: the image stays in LDS, one 8-wave workgroup per CU, waves walk 32-row blocks (vq_search_resident.inc)
 template <int DP, int METRIC>
 int launch_resident_t(const SearchParams &p, int H, int cus, hipStream_t s) {
-    const size_t lds = ResGeo<DP>::lds_bytes(p.res_img_floats);
+    const size_t lds = ResGeo<DP>::lds_bytes(p.res_img_floats, p.res_nbuf);
     auto kern = vq_search_resident<DP, METRIC>;
     static thread_local bool attr_done[kMaxDevices] = {};
     if (int rc = allow_big_lds(kern, attr_done)) return rc;
@@ -1077,6 +1077,12 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         p.loss_part = a->sq_err ? loss_part : nullptr;
         p.lse = lse;
         p.res_img_floats = res_img;
+        if (res_img) {
+            static const char *env = getenv("VQ_RES_SKEW");  // (diagnostic: start-up skew of the second wave per SIMD)
+            p.res_skew = env ? atoi(env) : 0;
+            const size_t full = ((size_t)res_img + 8 * (DP / 16) * 512) * 4 + 2 * 8 * 32 * 4;  // a slab buffer per slab of a block
+            p.res_nbuf = (DP < 128 && full <= 160 * 1024) ? DP / 16 : 1;
+        }
         rc = launch_search(DP, waves, p, a->H, 1, a->metric, s);
         if (rc) return rc;
         if (a->sq_err) {
