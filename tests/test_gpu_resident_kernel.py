@@ -31,8 +31,8 @@ SHAPES = [
     (1, 140000, 256, 64),      # cfg1's codebook at a row count that fills the chip
     (1, 262144, 256, 64),
     (1, 150001, 256, 128),     # Dp = 128: one accumulator, image 135 KB
-    (1, 140000, 512, 64),      # the largest image at Dp = 64
-    (1, 140077, 512, 32),
+    (1, 140000, 224, 64),      # K not a multiple of 32 * 8
+    (1, 140077, 256, 32),
     (1, 140000, 100, 48),      # D is not the padded width (Dp = 64, one padding slab), K not a multiple of 32
     (1, 140000, 1, 16),        # one code
     (1, 131072, 33, 128),

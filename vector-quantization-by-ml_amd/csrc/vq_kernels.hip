@@ -218,13 +218,24 @@ int launch_persist_t(const SearchParams &p, int H, int cus, hipStream_t s) {
 template <int DP, int METRIC>
 int launch_resident_t(const SearchParams &p, int H, int cus, hipStream_t s) {
     const size_t lds = ResGeo<DP>::lds_bytes(p.res_img_floats, p.res_nbuf);
-    auto kern = vq_search_resident<DP, METRIC>;
-    static thread_local bool attr_done[kMaxDevices] = {};
-    if (int rc = allow_big_lds(kern, attr_done)) return rc;
     const long long nwb = (p.M + 31) / 32;
     long long gx = cus / H;
     if (gx < 1) gx = 1;
     if (gx > (nwb + 7) / 8) gx = (nwb + 7) / 8;
+    if constexpr (DP < 128) {
+        if (p.res_nbuf > 1) {  // a slab buffer per slab of a block
+            auto kern = vq_search_resident<DP, METRIC, true>;
+            static thread_local bool attr_done_r[kMaxDevices] = {};
+            if (int rc = allow_big_lds(kern, attr_done_r)) return rc;
+            hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)H, 1), dim3(512), lds, s, p);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "vq_search_resident launch");
+            return 0;
+        }
+    }
+    auto kern = vq_search_resident<DP, METRIC, false>;
+    static thread_local bool attr_done[kMaxDevices] = {};
+    if (int rc = allow_big_lds(kern, attr_done)) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)H, 1), dim3(512), lds, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "vq_search_resident launch");
@@ -443,6 +454,9 @@ int resident_image_for(const vq_args *a, int DP, bool lse, int cus) {
     if (a->flags & (VQ_F_STE | VQ_F_FORCE_SIMPLE | VQ_F_FORCE_SPLIT | VQ_F_X_F16 | VQ_F_X_BF16)) return 0;
     if (a->D % 16 || a->x_rs % 4 || a->x_hs % 4 || !aligned16(a->x)) return 0;
     if (a->out_rs % 4 || a->out_hs % 4 || !aligned16(a->out) || a->cb_hs % 4 || !aligned16(a->cb)) return 0;
+    const int nsub_k = (a->K + kTileCodes - 1) / kTileCodes;
+    if (nsub_k < DP / 16) return 0;  // (the sweep's first Dp / 16 sub-tiles carry the next block's slabs)
+    if (nsub_k > 8) return 0;        // measured (gpurun_out/r3/t5_res_ab.log): from K = 512 on the tile-streaming kernels are ahead again
     const int img = resident_image_floats(a->K, DP);
     const size_t lds = ((size_t)img + 8 * 512) * 4 + 2 * 8 * 32 * 4;
     if (lds > 160 * 1024) return 0;
