@@ -97,3 +97,31 @@ def test_key_planes_need_no_init_and_no_atomics(H, M, K, D, metric):
     p1 = native.search_key_planes(x, cb[:, half:].contiguous(), metric=metric, idx_offset=half)
     fin2 = native.finalize_keys(x, cb, torch.cat([p0, p1], dim=0), metric=metric)
     assert torch.equal(fin2["idx"], fin1["idx"]) and torch.equal(fin2["out"], fin1["out"])
+
+
+@pytest.mark.parametrize("M,K,D,Q", [(70000, 1024, 256, 4), (80000, 256, 256, 3), (140000, 512, 200, 2), (65536, 1024, 256, 3)])
+@pytest.mark.parametrize("training", [False, True])
+def test_residual_stacks_with_awkward_row_counts(M, K, D, Q, training):
+    """Residual stacks cannot split K; a row count just above a multiple of 256 x CUs runs on 128-row (4-wave) workgroups so
+    that the remainder costs half a round.  Whatever the workgroup size: equal to the stages searched one by one with the
+    one-thread-per-row kernel and the reference's residual arithmetic (residual_vq.py:232-233, vector_quantize_pytorch.py:273)."""
+    from vector_quantization import native
+
+    native.load()
+    g = torch.Generator(device=DEV).manual_seed(M + K + Q)
+    x = torch.randn((1, M, D), device=DEV, generator=g)
+    cbs = torch.stack([torch.randn((K, D), device=DEV, generator=g) * 2.0 ** (-i / 2.0) for i in range(Q)])[None].contiguous()
+    r = native.quantize(x, cbs, ste=training, want_sq_err=training, want_best=True)
+    res, out = x, torch.zeros_like(x)
+    for q in range(Q):
+        s = native.quantize(res, cbs[:, q:q + 1].contiguous(), flags=native.F_FORCE_SIMPLE, want_best=True)
+        assert torch.equal(r["idx"][..., q], s["idx"][..., 0]), f"stage {q}"
+        assert torch.equal(r["best"][..., q].view(torch.int32), s["best"][..., 0].view(torch.int32)), f"stage {q}"
+        code = s["out"]
+        quant = res + (code - res) if training else code
+        if training:
+            err = (code - res).double().pow(2).sum()
+            torch.testing.assert_close(r["sq_err"][q], err, rtol=1e-6, atol=0)
+        res = res - quant
+        out = out + quant
+    assert torch.equal(r["out"], out)

@@ -1065,6 +1065,21 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
             waves = 4;
             wgs = (long long)a->H * ((a->M + 127) / 128);
         }
+        // Residual stacks cannot split K (every stage needs the whole codebook per row), so a row count just above a multiple of
+        // cus x 256 used to pay a whole extra round of 8-wave workgroups.  Two 4-wave workgroups share a CU at the pace of one
+        // 8-wave workgroup, and a LONE 4-wave workgroup (one wave per SIMD: the matrix pipe to itself) finishes its 128 rows in
+        // about half a round -- so with 128-row workgroups the remainder costs half a round instead of a whole one whenever it
+        // fits one workgroup per CU (M = 70 000 at cfg4's shape: 2 rounds -> ~1.55).
+        if (waves == 8 && DP == 256 && a->Q > 1) {
+            const long long nblk4 = (long long)a->H * ((a->M + 127) / 128);
+            const long long full = nblk4 / (2ll * cus), rem = nblk4 % (2ll * cus);
+            const double t8 = (double)((wgs + cus - 1) / cus);
+            const double t4 = (double)full + (rem == 0 ? 0.0 : (rem <= cus ? 0.55 : 1.0));
+            if (t4 < 0.97 * t8) {
+                waves = 4;
+                wgs = nblk4;
+            }
+        }
 #ifdef VQ_EXP_WAVES
         waves = VQ_EXP_WAVES;  // diagnostic builds only
 #endif
