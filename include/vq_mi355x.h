@@ -48,7 +48,7 @@ extern "C" {
  * inside each group of 8 dims the even dims come first, then the odd ones, values pre-scaled by -2 (Euclid) or 1 (dot);
  * float Dp of each row holds |c|^2 (d-ordered fmaf chain; +inf for the padding rows), float Dp + 1 holds 1.0, float
  * Dp + 2 the same chain under either metric; the last 16 bytes of the image hold a "some code is non-finite" word.
- * D > 512: ceil(D / 256) such images back to back, one per 256-dim slice of the rows (the last one as wide as it needs).
+ * D > 512: ceil(D / 512) such images back to back, one per 512-dim slice of the rows (the last one as wide as it needs).
  * Returns the number of floats ONE packed codebook occupies (including over-copy slack), 0 on bad args.
  */
 int64_t vq_packed_floats(int K, int D);
@@ -99,7 +99,7 @@ int64_t vq_workspace_bytes(int H, int64_t M, int Q);
 /*
  * The same for rows WIDER than 512 dims (Q == 1).  The reference has no limit on the row width (cdist / einsum over any
  * D, codebooks.py:122-129,386); here a distance is one k-ordered fmaf chain over all dims, so such rows are swept in
- * 256-dim slices and the chains of one (row chunk) x (code chunk) wait in the workspace between two slices
+ * 512-dim slices and the chains of one (row chunk) x (code chunk) wait in the workspace between two slices
  * (at most 512 MiB beyond vq_workspace_bytes(H, M, 1)).  For D <= 512 this is vq_workspace_bytes(H, M, 1).
  */
 int64_t vq_workspace_bytes_wide(int H, int64_t M, int K, int D);
@@ -126,7 +126,7 @@ int vq_nearest_f32(const vq_args *a, void *stream);
 int vq_residual_f32(const vq_args *a, void *stream);
 
 /* Largest number of residual stages ONE fused launch can hold for rows of dimension D (the winners' indices and, with
- * want_sq_err, the loss partials of every stage live in the CU's 160 KiB of LDS).  0 for D > 512 (such rows are searched one stage per call, in 256-dim slices).
+ * want_sq_err, the loss partials of every stage live in the CU's 160 KiB of LDS).  0 for D > 512 (such rows are searched one stage per call, in 512-dim slices).
  * A caller with more stages (the reference's ResidualVQ has no limit, residual_vq.py:212-243) runs its layers one
  * launch each instead.  Host-side arithmetic only: no device call. */
 int vq_max_fused_stages(int D, int want_sq_err);

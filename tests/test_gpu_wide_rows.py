@@ -1,7 +1,8 @@
 """GPU: rows WIDER than 512 dims (the reference has no width limit: cdist / einsum over any D, codebooks.py:122-129,386).
 
-Such rows are swept in 256-dim slices whose distance chains wait in the workspace between two launches
-(vq_search_mfma<256, 8, metric, 0, false, 0, WIDE>, csrc/vq_kernels.hip run_search_keys_wide); the chain of a (row, code)
+Such rows are swept in 512-dim slices whose distance chains wait in the workspace between two launches
+(vq_search_pair512<metric, false, 0, WIDE> -- vq_search_mfma<.., WIDE> for short sweeps and for the last, narrower slice --
+csrc/vq_kernels.hip run_wide); the chain of a (row, code)
 pair is still the oracle's k-ordered fmaf chain, so indices AND winning distances must be bit-identical to the CPU oracle.
 Covered: D just above 512 / not a multiple of 4 / several slices, K below one sub-tile and across two code chunks
 (4096 codes each), split-K launches (few row blocks) and unsplit ones (many), several row chunks (heads shrink the chunk),
@@ -146,7 +147,7 @@ def test_wide_rows_workspace_is_checked():
     H, M, K, D = 1, 256, 64, 600
     assert lib.vq_workspace_bytes_wide(H, M, K, D) > lib.vq_workspace_bytes(H, M, 1)
     assert lib.vq_workspace_bytes_wide(H, M, K, 512) == lib.vq_workspace_bytes(H, M, 1)
-    assert lib.vq_packed_floats(K, D) == 2 * lib.vq_packed_floats(K, 256) + lib.vq_packed_floats(K, D - 512)  # 256 + 256 + 88 dims
+    assert lib.vq_packed_floats(K, D) == lib.vq_packed_floats(K, 512) + lib.vq_packed_floats(K, D - 512)  # slices of 512 + 88 dims
     x = torch.randn((H, M, D), device=DEV)
     cb = torch.randn((H, 1, K, D), device=DEV)
     packed = native.pack_codebooks(cb, 0)

@@ -173,11 +173,20 @@ int launch_search_m(const SearchParams &p, int H, int splits, int metric, hipStr
     return launch_search_t<DP, WAVES, VQ_METRIC_DOT, 0>(p, H, splits, s);
 }
 
+// VQ_SINGLE_WAVE_512=1 in the environment selects the one-wave-per-row-block kernel for D > 256 (A/B measurements)
+bool use_pair512() {
+    static const bool off = getenv("VQ_SINGLE_WAVE_512") != nullptr;
+    return !off;
+}
+
+// The wave-pair kernel runs wave B one tile behind wave A: one extra step per sweep.  Worth it from 8 tiles per sweep on.
+bool pair_selected(int DP, int Q, int tiles_per_sweep) { return DP == 512 && Q == 1 && tiles_per_sweep >= 8 && use_pair512(); }
+
 // 256 < D <= 512: dims split over wave pairs (vq_search_pair.inc); 8 waves = 4 pairs = 128 rows per workgroup
-template <int METRIC, bool LSE = false, int XT = 0>
+template <int METRIC, bool LSE = false, int XT = 0, int WIDE = 0>
 int launch_pair_t(const SearchParams &p, int H, int splits, hipStream_t s) {
     const size_t lds = PairGeo::lds_bytes(1, false);
-    auto kern = vq_search_pair512<METRIC, LSE, XT>;
+    auto kern = vq_search_pair512<METRIC, LSE, XT, WIDE>;
     static thread_local bool attr_done[kMaxDevices] = {};
     if (int rc = allow_big_lds(kern, attr_done)) return rc;
     dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)H, (unsigned)splits);
@@ -297,7 +306,7 @@ int launch_ce_bwd_m(const CeBwdParams &p, int H, int metric, hipStream_t s) {
 #define VQ_EXP_RESIDENT_MIN_ROWS_PER_CU 512  // rows per CU from which the resident-codebook kernel takes a small codebook
 #endif
 #ifndef VQ_EXP_WIDE_SLICE
-#define VQ_EXP_WIDE_SLICE 256
+#define VQ_EXP_WIDE_SLICE 512  // dims per slice of rows wider than 512 dims (256: the round-2 scheme, twice the accumulator traffic)
 #endif
 constexpr int kWideSlice = VQ_EXP_WIDE_SLICE;                // dims per slice: 512 (4-wave workgroups) or 256 (8-wave)
 constexpr int kWideWaves = kWideSlice == 512 ? 4 : 8;
@@ -384,6 +393,14 @@ template <> int part_search<512>(int, const SearchParams &p, int H, int splits, 
 }
 template <> int part_wide<512>(int wide, const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
 #if VQ_EXP_WIDE_SLICE == 512
+    // a 512-dim slice of wider rows: the wave-pair kernel (two waves per SIMD, accumulator hand-off) when the sweep is long
+    // enough for its extra pipeline step, else the one-wave kernel
+    if (pair_selected(512, 1, p.tiles_per_split)) {
+        const bool eu = metric == VQ_METRIC_EUCLID;
+        if (wide == 1) return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 0, 1>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 0, 1>(p, H, splits, s);
+        if (wide == 3) return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 0, 3>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 0, 3>(p, H, splits, s);
+        return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 0, 2>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 0, 2>(p, H, splits, s);
+    }
     return launch_wide_any<512>(wide, p, H, splits, metric, s);
 #else
     (void)wide; (void)p; (void)H; (void)splits; (void)metric; (void)s;
@@ -420,15 +437,6 @@ namespace vqi {
 thread_local char g_err[512] = "";
 }
 namespace {
-
-// VQ_SINGLE_WAVE_512=1 in the environment selects the one-wave-per-row-block kernel for D > 256 (A/B measurements)
-bool use_pair512() {
-    static const bool off = getenv("VQ_SINGLE_WAVE_512") != nullptr;
-    return !off;
-}
-
-// The wave-pair kernel runs wave B one tile behind wave A: one extra step per sweep.  Worth it from 8 tiles per sweep on.
-bool pair_selected(int DP, int Q, int tiles_per_sweep) { return DP == 512 && Q == 1 && tiles_per_sweep >= 8 && use_pair512(); }
 
 // Plain inference call at Dp = 256 (one stage, no straight-through, no loss, aligned fp32 rows, >= 32 sub-tiles per sweep,
 // several row blocks per CU): persistent workgroups that copy block b's winners during block b + 1's sweep.
