@@ -16,7 +16,11 @@ import json
 import os
 import sys
 
-KERNEL = "vq_search_"  # vq_search_mfma<...> or, for 256 < D <= 512, vq_search_pair512<...>
+KERNEL = "vq_search_"  # vq_search_mfma<...>, vq_search_persist<...> or, for 256 < D <= 512, vq_search_pair512<...>
+RND = os.environ.get("VQ_ROUND", "r03")
+# dispatches of the search kernel(s) per SEARCH: rows wider than 512 dims are swept in ceil(D / 512) launches, and the HBM
+# traffic of one search is the SUM over them (round 2 reported the mean per dispatch there: VERDICT r2 weak #3)
+LAUNCHES_PER_SEARCH = {"wide1024": 2}
 
 
 def find(raw, wl, sub, pattern):
@@ -52,7 +56,7 @@ def main():
         stats = find(raw, wl, "stats", "*kernel_stats.csv")
         if stats:
             rows = list(csv.reader(open(stats, newline="")))
-            with open(os.path.join(out, f"r02_{wl}_kernel_stats.csv"), "w", newline="") as f:
+            with open(os.path.join(out, f"{RND}_{wl}_kernel_stats.csv"), "w", newline="") as f:
                 csv.writer(f, quoting=csv.QUOTE_MINIMAL).writerows(rows[:8])
         pmc = {}
         kernel_names = []
@@ -65,15 +69,18 @@ def main():
             pmc.setdefault("_dispatches", {}).update(counts)
             kernel_names = names or kernel_names
         if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-            hbm = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            nl = LAUNCHES_PER_SEARCH.get(wl, 1)
+            hbm = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 * nl
             pmc["hbm_bytes_per_launch"] = hbm
+            pmc["launches_per_search"] = nl
             traffic[wl] = {
-                "hbm_bytes_per_launch": int(round(hbm)), "FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"],
+                "hbm_bytes_per_launch": int(round(hbm)), "launches_per_search": nl,
+                "FETCH_SIZE_KB": pmc["FETCH_SIZE"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"],
                 "kernel": kernel_names,
                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --workload %s --no-legs "
                         "--no-cpu-baseline --no-sharded --steps 20 --warmup 5`, mean over the search kernel's dispatches; gfx950 "
                         "correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request -> doubled; WRITE_SIZE "
-                        "exact. hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024" % wl}
+                        "exact. hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 x launches_per_search (the counters are means per dispatch)" % wl}
         pmc["kernel"] = kernel_names
         trace = find(raw, wl, "stats", "*kernel_trace.csv")
         if trace:
@@ -85,17 +92,20 @@ def main():
                     if KERNEL in row.get("Kernel_Name", ""):
                         durs.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
             durs = [d for _s, d in sorted(durs)]
-            if len(durs) >= 33:
-                timed = durs[-33:-13]
-                pmc["kernel_trace_timed_steps"] = {"launches": len(timed), "mean_ns": sum(timed) / len(timed), "min_ns": min(timed),
-                                                   "max_ns": max(timed), "all_launches": len(durs), "mean_all_ns": sum(durs) / len(durs)}
+            nl = LAUNCHES_PER_SEARCH.get(wl, 1)
+            if len(durs) >= 33 * nl:
+                timed = durs[-33 * nl:-13 * nl]
+                timed = [sum(timed[i * nl:(i + 1) * nl]) for i in range(20)]  # one entry per search
+                pmc["kernel_trace_timed_steps"] = {"launches": len(timed), "launches_per_search": nl, "mean_ns": sum(timed) / len(timed),
+                                                   "min_ns": min(timed), "max_ns": max(timed), "all_launches": len(durs),
+                                                   "mean_all_ns": sum(durs) / len(durs) * nl}
         bench_line = os.path.join(raw, f"{wl}.bench_under_trace.json")
         if os.path.exists(bench_line):
             try:
                 pmc["bench_line_under_kernel_trace"] = json.loads(open(bench_line).read().strip().splitlines()[-1])["roofline"]
             except Exception:
                 pass
-        json.dump(pmc, open(os.path.join(out, f"r02_{wl}_pmc.json"), "w"), indent=1)
+        json.dump(pmc, open(os.path.join(out, f"{RND}_{wl}_pmc.json"), "w"), indent=1)
     tpath = os.path.join(out, "traffic.json")
     merged = {}
     if os.path.exists(tpath):  # a partial re-run (some workloads only) keeps the others' entries
