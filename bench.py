@@ -22,8 +22,9 @@ Objects in the JSON line beside the contract's keys:
                 (north-star roofline shape), cfg3a / cfg3b (multi-head, per-head dim 64 / 512), cfg4 (ResidualVQ) --
                 value, ms_per_step, roofline and a CPU-oracle parity gate per leg; plus wide1024 (rows of 1024 dims:
                 not a BASELINE config, the sliced sweep for rows wider than one launch holds).
-  sharded_k65536  BASELINE configs[4]: K = 65536, D = 512 sharded over the N ranks (packed-key MIN all-reduce or
-                one-hop all-gather + local min); at N = 1 the full-codebook 1-GPU figure of the same kernels.
+  sharded_k65536  BASELINE configs[4]: K = 65536, D = 512 sharded over the N ranks (packed-key planes, MIN all-reduce or
+                one-hop all-gather + MIN in the finalize), M = 8192 and M = 65536, each with per-phase times (search /
+                exchange / finalize / host enqueue); at N = 1 the full-codebook 1-GPU figure of the same kernels.
 """
 from __future__ import annotations
 
@@ -309,7 +310,9 @@ def run_workload(name, args, device, rank, world, want_parity):
     ab = algorithmic_bytes_per_step(w)
     roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                 frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic_record(name),
-                kernel=("vq_search_mfma<256, 8, .., WIDE> x slices (the last one finishes the call)" if head_dim(w) > 512 else
+                traffic_source="profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload's bench command "
+                               "(tools/profile_round.sh), per search; a recorded measurement, not taken during this run",
+                kernel=("vq_search_pair512<.., WIDE> x 512-dim slices (the last one finishes the call)" if head_dim(w) > 512 else
                         "vq_search_pair512" if (head_dim(w) > 256 and w.get("Q", 1) == 1) else
                         "vq_search_persist" if (128 < head_dim(w) <= 256 and w.get("Q", 1) == 1 and 1024 <= w["K"] <= 3072) else
                         "vq_search_mfma"),
