@@ -14,10 +14,16 @@
     } while (0)
 
 int main(void) {
-    /* packed image: Kp x (Dp + 4) floats + slack; one image per 256-dim slice beyond 512 dims */
+    /* packed image: Kp x (Dp + 4) floats + slack; one image per 512-dim slice beyond 512 dims */
     CHECK(vq_packed_floats(1024, 256) >= 1024 * 260);
     CHECK(vq_packed_floats(1000, 100) >= 1024 * 132);
-    CHECK(vq_packed_floats(64, 600) == 2 * vq_packed_floats(64, 256) + vq_packed_floats(64, 88));
+    CHECK(vq_packed_floats(64, 600) == vq_packed_floats(64, 512) + vq_packed_floats(64, 88));
+    {   /* key planes: host arithmetic, one plane when nothing is searched */
+        vq_args z;
+        memset(&z, 0, sizeof(z));
+        CHECK(vq_key_planes(&z) == 1);
+        CHECK(vq_finalize_key_planes_f32(&z, NULL, 0, NULL) == VQ_E_BADARG);
+    }
     CHECK(vq_packed_floats(0, 32) == 0);
     CHECK(vq_workspace_bytes(1, 1024, 1) >= 1024 * 8);
     CHECK(vq_workspace_bytes(0, 10, 1) == 0);

@@ -3,6 +3,8 @@
 //
 //   pack      natural codebook [K, D]  ->  packed image  [Kp][Dp + 4]  (even/odd de-interleave inside
 //             each group of 8 dims, pre-scaled by -2 for Euclid, |c|^2 in float Dp of every row)
+//             (+ a "some code is non-finite" word per image: ATen's argmax rule for NaN / inf inputs is restored out of line,
+//             see repair_nonfinite_rows in vq_search.inc)
 //   search    one wave owns 32 rows of x for the whole sweep; their fp32 values live in REGISTERS as
 //             v_mfma_f32_32x32x2_f32 B-fragments (Dp/2 VGPRs per lane).  The workgroup streams ~33 KB
 //             tiles of the packed image HBM/L2 -> LDS with buffer_load ... lds (LDS-DMA, double
@@ -18,12 +20,14 @@
 // chain  fma(1*|c|^2 .. fma(|x|^2*1, fma(x_{D-1}, -2c_{D-1}, ... fma(x_0, -2c_0, 0))))  which is what
 // v_mfma_f32_32x32x2_f32 computes; norms are d-ordered fmaf chains; sqrt is correctly rounded.
 //
-// Source layout (ONE translation unit; the .inc files are included below inside the anonymous namespace, in this order):
+// Source layout (ONE source file: the .inc files are included below inside the anonymous namespace, in this order; the file
+// is compiled either whole or once per build part -- see "Build parts"):
 //   vq_common.inc        constants, error strings, padded-dim table, packed (value, index) keys
 //   vq_pack.inc          natural codebook -> packed image
 //   vq_search.inc        the hot kernel (tile geometry, LDS-DMA staging, MFMA fragment pipeline, tie-exact epilogue, finalize)
 //   vq_search_pair.inc   the same search for 256 < D <= 512 with the dims split over a pair of waves (accumulator hand-off)
 //   vq_search_persist.inc  inference search at Dp = 256 with block b's gather hidden inside block b + 1's sweep
+//   vq_search_resident.inc small codebooks: the packed image stays in LDS, no barriers, rows streamed past it by LDS-DMA slabs
 //   vq_similarity.inc    the same sweep with the similarity / online-softmax epilogues, fused cross-entropy backward
 //   vq_finalize_ema.inc  scalar fallback search, finalize-from-keys, loss reduction, EMA codebook update
 //   this file            host-side dispatch and the C ABI (include/vq_mi355x.h)
