@@ -193,3 +193,91 @@ def test_sharded_module_native_two_processes_on_the_gpu(tmp_path, oracle, reduct
         sl = slice(r * kl, (r + 1) * kl)
         np.testing.assert_allclose(z["cs"], ref._codebook.cluster_size.cpu().numpy()[:, sl], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(z["emb"], ref._codebook.embeddings.detach().cpu().numpy()[:, sl], rtol=1e-4, atol=1e-5)
+
+
+def _worker_dead_codes(rank, world, port, out_dir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "vector-quantization-by-ml_amd"), os.path.join(root, "tests"),
+              os.path.join(root, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import vector_quantization as vq
+    from gen import make_x
+    from helpers import OracleBackend
+    from vector_quantization import search
+    from vector_quantization.codebooks import CodebookParams
+
+    search.set_backend(OracleBackend)
+    K, D = 64, 16
+    kl = K // world
+    x = make_x((4, 60, D), "S")
+    g = torch.Generator().manual_seed(5)
+    # rank 0's codes sit on the data, rank 1's far away: only rank 1 owns dead codes after an EMA step
+    near = x.reshape(-1, D)[torch.randperm(240, generator=g)[:kl]].clone()
+    far = torch.randn((kl, D), generator=g) + 50.0
+    params = CodebookParams(dim=D, codebook_size=K, threshold_ema_dead_code=2, decay=0.5)
+    mod = vq.VectorQuantize(dim=D, codebook_params=params, codebook_shard_group=True, codebook_shard_gather="replicated")
+    with torch.no_grad():
+        mine = near if rank == 0 else far
+        mod._codebook.embeddings.copy_(mine[None])
+        mod._codebook.embed_avg.copy_(mine[None])
+        mod._codebook.cluster_size.fill_(3.0 if rank == 0 else 0.0)
+    before = mod._codebook.embeddings.detach().clone()
+    mod.train()
+    torch.manual_seed(100 + rank)
+    tables = []
+    for _ in range(3):  # every step: search against the gathered table, EMA update of the owned codes, re-seeding of dead ones
+        q, idx, loss = mod(x)
+        tables.append(mod.gather_table().clone())
+    mod.eval()
+    with torch.no_grad():
+        q, idx, _ = mod(x)
+    table = mod.gather_table()
+    np.savez(os.path.join(out_dir, f"d{rank}.npz"), before=before.numpy(), after=mod._codebook.embeddings.detach().numpy(),
+             table=table.numpy(), idx=idx.numpy(), q=q.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dead_code_reseeding_on_one_rank_keeps_the_shards_in_lockstep(tmp_path, oracle):
+    """with threshold_ema_dead_code > 0 only the ranks that OWN dead codes re-seed them.  The cached gather table
+    must still be refreshed collectively (every rank's shard changes in every EMA step) -- no deadlock, identical tables on
+    all ranks, equal to the concatenation of the shards, and the far-away shard's dead codes were moved onto the data."""
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker_dead_codes, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    z = [np.load(tmp_path / f"d{r}.npz") for r in range(world)]
+    np.testing.assert_array_equal(z[0]["table"], z[1]["table"])
+    np.testing.assert_array_equal(z[0]["table"][0], np.concatenate([z[0]["after"][0], z[1]["after"][0]]))
+    np.testing.assert_array_equal(z[0]["idx"], z[1]["idx"])
+    np.testing.assert_array_equal(z[0]["q"], z[1]["q"])
+    moved = np.abs(z[1]["after"] - z[1]["before"]).max(axis=-1) > 1.0
+    assert moved.sum() >= 16, "rank 1's dead codes must have been re-seeded from the batch"
+    assert np.abs(z[1]["after"]).max() < 20.0  # ... onto the data (rows ~ N(0, 1)), away from the +50 offset
+
+
+def test_sharded_codebook_refuses_stochastic_sampling():
+    """the sharded path decodes argmax keys only -- Gumbel sampling must be refused, not silently replaced."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "vector-quantization-by-ml_amd"))
+    import vector_quantization as vq
+    from vector_quantization.codebooks import CodebookParams, GumbelParams
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        params = CodebookParams(dim=8, codebook_size=16, gumbel_params=GumbelParams(stochastic=True, temperature=1.0))
+        with pytest.raises(NotImplementedError, match="stochastic_sampling"):
+            vq.VectorQuantize(dim=8, codebook_params=params, codebook_shard_group=True)
+        vq.VectorQuantize(dim=8, codebook_params=CodebookParams(dim=8, codebook_size=16), codebook_shard_group=True)
+    finally:
+        dist.destroy_process_group()
