@@ -79,6 +79,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 struct DevInfo {
     int cus = 0;
+    int clock_mhz = 2400;  // shader clock (hipDeviceProp_t::clockRate), what the launch plans price a sub-tile with
     bool ok = false;
     char name[128] = "";
 };
@@ -95,6 +96,7 @@ const DevInfo &dev_info() {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
             info.cus = prop.multiProcessorCount;
+            if (prop.clockRate > 0) info.clock_mhz = prop.clockRate / 1000;
             snprintf(info.name, sizeof(info.name), "%s", prop.gcnArchName);
             info.ok = true;
             cached_dev = dev;
@@ -597,6 +599,16 @@ int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipS
 //  still one slot of the rounds model below, to within a few percent.)
 inline int fused_rows_per_wg(int DP) { return DP == 512 ? 128 : 256; }
 
+// Time of one 32-code sub-tile of an 8-wave workgroup, microseconds, from the device's own clock instead of a constant
+// measured on one box: two waves share a SIMD and each issues Dp / 2 + 1 fp32 MFMAs of 64 cycles per sub-tile (Dp = 256 at
+// 2.4 GHz: 6.9 us; the 7.2 us measured in round 2 included the sweep's ~4 % of vector work).  Only the RATIO between a
+// sub-tile and the finalize's HBM time enters the plans.
+inline double sub_tile_us(int DP) {
+    const DevInfo &di = dev_info();
+    const double mhz = di.ok && di.clock_mhz > 0 ? (double)di.clock_mhz : 2400.0;
+    return 1.045 * 2.0 * (DP / 2 + 1) * 64.0 / mhz;
+}
+
 // Quantisation of the grid: with one workgroup per CU the launch runs in rounds of `cus` workgroups, and a row count just
 // above a multiple of cus x rows-per-workgroup pays a whole extra round (M = 70 000 at D = 256: 274 workgroups = 2 rounds for
 // 1.07 rounds of work).  Splitting K over S workgroups per row block makes the rounds shorter and fuller at the price of one
@@ -608,7 +620,7 @@ int plan_k_split(int DP, int H, long long M, int K, int D, int cus, double *cost
     const int nsub = (K + kTileCodes - 1) / kTileCodes;
     if (cost) *cost = *fused_cost = (double)((nblk + cus - 1) / cus) * (1.5 + nsub + 1.2);
     if (nblk * 2 <= cus || nsub < 16) return 1;  // (few workgroups: the older rule below splits until the chip is full)
-    const double sub_us = 7.2 * DP / 256.0;  // one sub-tile of all the workgroup's waves, microseconds (measured at Dp = 256)
+    const double sub_us = sub_tile_us(DP);  // one sub-tile of all the workgroup's waves, microseconds
     const double tail = 3.0 + (double)M * H * D * 8.0 / 5e6 / sub_us;  // keys init + finalize kernels
     auto rounds = [&](long long wgs) { return (double)((wgs + cus - 1) / cus); };
     const double fused = rounds(nblk) * (1.5 + nsub + 1.2);
@@ -644,7 +656,7 @@ long long plan_main_tail(int DP, int H, long long M, int K, int D, int cus) {
     if (st > nsub / 8) st = nsub / 8;
     if (st < 1) st = 1;
     const int per = (nsub + st - 1) / st;
-    const double sub_us = 7.2 * DP / 256.0;
+    const double sub_us = sub_tile_us(DP);
     const double tail = (double)((rem * st + cus - 1) / cus) * (1.5 + per) + 3.0 + (double)(rem * rpw) * D * 8.0 / 5e6 / sub_us;
     // (rem counts workgroups of all heads together)
     const double hybrid = (double)full * (1.5 + nsub + 1.2) + tail;
