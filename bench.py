@@ -281,6 +281,8 @@ def run_workload(name, args, device, rank, world, want_parity):
         # settle phase ran the search itself, and its ~50 slower launches sat in the rocprofv3 --stats average)
         ga = torch.randn((4096, 4096), device=device)
         gb = torch.randn((4096, 4096), device=device)
+        torch.mm(ga, gb)  # (the library's first call loads its kernels: not part of the settle time)
+        torch.cuda.synchronize(device)
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
             for _ in range(4):
