@@ -276,19 +276,14 @@ def run_workload(name, args, device, rank, world, want_parity):
     mod = build_module(w, device)
     x = torch.randn(w["x_shape"], generator=torch.Generator().manual_seed(1234 + rank)).to(device)
     with torch.no_grad():
-        # not part of W or K: ~60 ms of fp32 matrix load lets the chip's clock ramp up (DVFS).  A library GEMM, NOT the search
-        # kernel: a profiler's per-kernel average of this command then contains steady-state launches only (round 2's
-        # settle phase ran the search itself, and its ~50 slower launches sat in the rocprofv3 --stats average)
-        ga = torch.randn((4096, 4096), device=device)
-        gb = torch.randn((4096, 4096), device=device)
-        torch.mm(ga, gb)  # (the library's first call loads its kernels: not part of the settle time)
-        torch.cuda.synchronize(device)
+        # not part of W or K: ~60 ms of the workload itself let the chip's clock ramp up (DVFS).  (Round 3 tried a library
+        # GEMM here so that a profiler's per-kernel average would hold steady-state launches only: the 1-ms search launches
+        # that follow a GEMM burst run 7 % SLOWER for tens of milliseconds -- profiles/r03 notes -- so the settle phase stays
+        # the search kernel, and `rocprofv3 --stats` averages of this command include its ~55 ramp-up launches.)
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
-            for _ in range(4):
-                torch.mm(ga, gb)
+            mod(x)
             torch.cuda.synchronize(device)
-        del ga, gb
         for _ in range(args.warmup):
             mod(x)
         torch.cuda.synchronize(device)
