@@ -168,6 +168,35 @@ def test_fused_cross_entropy_backward(H, M, K, D, metric):
     assert bool((got[:, ::5] == 0).all()), "ignored rows must get exactly zero gradient"
 
 
+@pytest.mark.parametrize("H,M,K,D", [(1, 128, 32, 256), (1, 1000, 1000, 256), (2, 333, 1030, 200), (1, 4097, 64, 132),
+                                     (3, 129, 7, 256), (1, 70000, 96, 256)])
+@pytest.mark.parametrize("metric", [0, 1])
+def test_cross_entropy_backward_wave_pair_kernel_equals_one_wave_kernel(H, M, K, D, metric):
+    """Dp = 256: the wave-pair kernel (S sweep and G sweep on two waves, weights handed over through LDS) runs the same chains
+    as the one-wave kernel (VQ_CE_NO_ROLES=1) -- equal bits, at ragged row counts, codebook tails and zero distances."""
+    import os
+    native = _native()
+    x, cb = make_x((H, M, D), "S"), make_codebook(H, K, D, "S")
+    if metric == 1:
+        x = x * 0.25
+    g = torch.Generator().manual_seed(5)
+    target = torch.randint(0, K, (H, M), generator=g)
+    target[:, ::7] = -1
+    if metric == 0 and M > 40:
+        x[0, 40] = cb[0, K // 2]  # a zero distance
+    xs, cbs, ts = x.cuda(), cb.cuda(), target.cuda()
+    lse, tl = native.softmax_stats(xs, cbs, metric=metric, target=ts)
+    coef = torch.tensor([0.5], device="cuda")
+    got = native.ce_backward(xs, cbs, lse, tl, ts, coef, metric=metric)
+    os.environ["VQ_CE_NO_ROLES"] = "1"
+    try:
+        ref = native.ce_backward(xs, cbs, lse, tl, ts, coef, metric=metric)
+    finally:
+        os.environ.pop("VQ_CE_NO_ROLES", None)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int32), ref.view(torch.int32))
+
+
 def test_fused_cross_entropy_backward_strided_heads():
     native = _native()
     rows, heads, d, K = 200, 3, 32, 96

@@ -42,6 +42,15 @@ def main():
     print(f"search (reference point)        {t:8.3f} ms  {flops / t / 1e9:7.1f} TFLOP/s")
     t = timed(lambda: native.softmax_stats(x, cb, target=tgt, packed=packed))
     print(f"softmax stats (CE forward)      {t:8.3f} ms  {flops / t / 1e9:7.1f} TFLOP/s")
+    lse, tl = native.softmax_stats(x, cb, target=tgt, packed=packed)
+    coef = torch.tensor([1.0 / M], device=dev)
+    for env in ("", "1"):
+        if env:
+            os.environ["VQ_CE_NO_ROLES"] = env
+        t = timed(lambda: native.ce_backward(x, cb, lse, tl, tgt, coef, packed=packed))
+        os.environ.pop("VQ_CE_NO_ROLES", None)
+        print(f"CE backward ({'one-wave kernel' if env else 'wave-pair roles'})  {t:8.3f} ms  {2 * flops / t / 1e9:7.1f} TFLOP/s "
+              f"({2 * flops / t / 1e9 / 157.3:.3f} of peak)")
     out = torch.empty((1, 65536, K), device=dev)
     t = timed(lambda: native.similarities(x[:, :65536], cb, packed=packed, out=out))
     print(f"similarities, 65536-row chunk   {t:8.3f} ms  {flops / 4 / t / 1e9:7.1f} TFLOP/s  {out.numel() * 4 / t / 1e6:7.1f} GB/s written")

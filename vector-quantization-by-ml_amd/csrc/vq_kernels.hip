@@ -302,8 +302,28 @@ int launch_ce_bwd_t(const CeBwdParams &p, int H, hipStream_t s) {
     return 0;
 }
 
+// Dp = 256: the two contractions on a pair of waves (two waves per SIMD); VQ_CE_NO_ROLES=1 keeps the one-wave kernel (A/B runs)
+template <int METRIC>
+int launch_ce_bwd_roles_t(const CeBwdParams &p, int H, hipStream_t s) {
+    const size_t lds = (size_t)CeRolesGeo::LDS_F * 4;
+    auto kern = vq_ce_backward_roles<METRIC>;
+    static thread_local bool attr_done[kMaxDevices] = {};
+    if (int rc = allow_big_lds(kern, attr_done)) return rc;
+    dim3 grid((unsigned)((p.M + 32 * CeRolesGeo::NB - 1) / (32 * CeRolesGeo::NB)), (unsigned)H, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_ce_backward_roles launch");
+    return 0;
+}
+
 template <int DP>
 int launch_ce_bwd_m(const CeBwdParams &p, int H, int metric, hipStream_t s) {
+    if constexpr (DP == 256) {
+        if (getenv("VQ_CE_NO_ROLES") == nullptr) {  // (read per call: tests switch between the two kernels in one process)
+            if (metric == VQ_METRIC_EUCLID) return launch_ce_bwd_roles_t<VQ_METRIC_EUCLID>(p, H, s);
+            return launch_ce_bwd_roles_t<VQ_METRIC_DOT>(p, H, s);
+        }
+    }
     if (metric == VQ_METRIC_EUCLID) return launch_ce_bwd_t<DP, VQ_METRIC_EUCLID>(p, H, s);
     return launch_ce_bwd_t<DP, VQ_METRIC_DOT>(p, H, s);
 }
