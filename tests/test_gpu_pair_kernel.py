@@ -93,3 +93,78 @@ def test_pair_kernel_ties_take_the_lowest_index(oracle):
     ri, rb = oracle.nearest(x[0, rows].cpu().numpy(), cb[0, 0].cpu().numpy(), 0)
     np.testing.assert_array_equal(r["idx"][0, rows, 0].cpu().numpy(), ri)
     assert np.array_equal(r["best"][0, rows, 0].cpu().numpy().view(np.uint32), rb.view(np.uint32))
+
+
+def _same_bits(a: torch.Tensor, b: torch.Tensor) -> bool:
+    an, bn = torch.isnan(a), torch.isnan(b)
+    z = torch.zeros_like(a)
+    return bool(torch.equal(an, bn)) and bool(torch.equal(torch.where(an, z, a).view(torch.int32), torch.where(bn, z, b).view(torch.int32)))
+
+
+RESIDUAL_CASES = [
+    # (H, Q, M, K, D, metric)     K >= 256: at least 8 tiles per sweep, else the launcher keeps the one-wave kernel
+    (1, 4, 300, 256, 512, 0),
+    (1, 3, 1000, 1000, 300, 0),
+    (1, 8, 129, 260, 384, 0),
+    (2, 2, 200, 512, 500, 0),
+    (1, 5, 4097, 288, 257, 0),
+    (1, 3, 500, 300, 512, 1),
+    (1, 20, 64, 256, 272, 0),     # the largest stack with squared errors the one-wave kernel (the witness) holds
+]
+
+
+@pytest.mark.parametrize("H,Q,M,K,D,metric", RESIDUAL_CASES)
+@pytest.mark.parametrize("training", [False, True])
+def test_residual_stacks_on_the_pair_kernel(oracle, H, Q, M, K, D, metric, training):
+    """256 < D <= 512, Q > 1 (round 3): both waves of a pair update their half of the residual after every sweep.  Bit-exact
+    against the CPU oracle's residual loop (residual_vq.py:212-243) and equal to the one-wave kernel (VQ_PAIR_NO_MULTI=1)."""
+    import os
+    native = _native()
+    g = torch.Generator().manual_seed(Q * 1000 + M + K + D)
+    x = torch.randn((H, M, D), generator=g)
+    cbs = torch.stack([torch.stack([torch.randn((K, D), generator=g) * 2.0 ** (-i / 2.0) for i in range(Q)]) for _ in range(H)])
+    xd, cd = x.to(DEV), cbs.to(DEV)
+    r = native.quantize(xd, cd, metric=metric, ste=training, want_sq_err=training)
+    os.environ["VQ_PAIR_NO_MULTI"] = "1"
+    try:
+        o = native.quantize(xd, cd, metric=metric, ste=training, want_sq_err=training)
+    finally:
+        os.environ.pop("VQ_PAIR_NO_MULTI", None)
+    torch.cuda.synchronize()
+    assert torch.equal(r["idx"], o["idx"])
+    assert _same_bits(r["best"], o["best"]) and _same_bits(r["out"], o["out"])
+    if training:
+        torch.testing.assert_close(r["sq_err"], o["sq_err"], rtol=1e-6, atol=0)
+    for h in range(H):
+        ref = oracle.rvq_forward(x[h].numpy(), cbs[h].numpy(), metric, training=training)
+        np.testing.assert_array_equal(r["idx"][h].cpu().numpy(), ref["idx"])
+        assert np.array_equal(r["best"][h].cpu().numpy().view(np.uint32), ref["best"].view(np.uint32))
+        np.testing.assert_array_equal(r["out"][h].cpu().numpy(), ref["out"])
+    if training and H == 1:
+        np.testing.assert_allclose(r["sq_err"].cpu().numpy().reshape(-1), ref["sq_err"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("training", [False, True])
+@pytest.mark.parametrize("poison_codes", [False, True])
+def test_residual_stacks_on_the_pair_kernel_non_finite(oracle, training, poison_codes):
+    """Rows holding NaN / inf (and a NaN inside a later stage's codebook): wave A dumps its half of the flagged rows, wave B
+    repairs them by the plain rule (ATen's argmax: the first NaN wins) -- equal to the oracle's residual loop."""
+    native = _native()
+    Q, M, K, D = 3, 700, 320, 400
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((M, D), generator=g)
+    cbs = torch.stack([torch.randn((K, D), generator=g) * 2.0 ** (-i / 2.0) for i in range(Q)])
+    x[5, 3] = float("nan")
+    x[64, 399] = float("inf")
+    x[699, 256] = float("-inf")
+    x[130, 0] = float("nan")
+    x[130, 300] = float("inf")
+    if poison_codes:
+        cbs[1, 17, 290] = float("nan")
+    with np.errstate(invalid="ignore", over="ignore"):
+        ref = oracle.rvq_forward(x.numpy(), cbs.numpy(), 0, training=training)
+    r = native.quantize(x[None].to(DEV), cbs[None].contiguous().to(DEV), ste=training, want_sq_err=training)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(r["idx"][0].cpu().numpy(), ref["idx"])
+    assert _same_bits(r["best"][0].cpu(), torch.from_numpy(ref["best"]))
+    assert _same_bits(r["out"][0].cpu(), torch.from_numpy(ref["out"]))

@@ -186,13 +186,18 @@ bool use_pair512() {
 }
 
 // The wave-pair kernel runs wave B one tile behind wave A: one extra step per sweep.  Worth it from 8 tiles per sweep on.
-bool pair_selected(int DP, int Q, int tiles_per_sweep) { return DP == 512 && Q == 1 && tiles_per_sweep >= 8 && use_pair512(); }
+// Residual stacks (round 3) as long as the winners of every stage fit its LDS (Q <= 26); VQ_PAIR_NO_MULTI=1: one-wave kernel (A/B).
+bool pair_selected(int DP, int Q, int tiles_per_sweep) {
+    if (!(DP == 512 && tiles_per_sweep >= 8 && use_pair512())) return false;
+    if (Q == 1) return true;
+    return getenv("VQ_PAIR_NO_MULTI") == nullptr && Q <= PairGeo::max_stages();  // (read per call: tests compare both kernels in one process)
+}
 
 // 256 < D <= 512: dims split over wave pairs (vq_search_pair.inc); 8 waves = 4 pairs = 128 rows per workgroup
-template <int METRIC, bool LSE = false, int XT = 0, int WIDE = 0>
+template <int METRIC, bool LSE = false, int XT = 0, int WIDE = 0, int MULTI = 0>
 int launch_pair_t(const SearchParams &p, int H, int splits, hipStream_t s) {
-    const size_t lds = PairGeo::lds_bytes(1, false);
-    auto kern = vq_search_pair512<METRIC, LSE, XT, WIDE>;
+    const size_t lds = PairGeo::lds_bytes(MULTI ? p.Q : 1);
+    auto kern = vq_search_pair512<METRIC, LSE, XT, WIDE, MULTI>;
     static thread_local bool attr_done[kMaxDevices] = {};
     if (int rc = allow_big_lds(kern, attr_done)) return rc;
     dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)H, (unsigned)splits);
@@ -205,6 +210,10 @@ int launch_pair_t(const SearchParams &p, int H, int splits, hipStream_t s) {
 #if VQ_OWN(4)  // (not a template: defining it instantiates the wave-pair kernels)
 int launch_pair_any(const SearchParams &p, int H, int splits, int metric, hipStream_t s) {
     const bool eu = metric == VQ_METRIC_EUCLID;
+    if (p.Q > 1) {  // residual stacks: eval (1) and straight-through (2) arithmetic, as in launch_search_m
+        if (p.ste) return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 0, 0, 2>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 0, 0, 2>(p, H, splits, s);
+        return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 0, 0, 1>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 0, 0, 1>(p, H, splits, s);
+    }
     if (p.xt == 1) return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 1>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 1>(p, H, splits, s);
     if (p.xt == 2) return eu ? launch_pair_t<VQ_METRIC_EUCLID, false, 2>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, false, 2>(p, H, splits, s);
     if (p.lse) return eu ? launch_pair_t<VQ_METRIC_EUCLID, true>(p, H, splits, s) : launch_pair_t<VQ_METRIC_DOT, true>(p, H, splits, s);
