@@ -169,11 +169,14 @@ def test_fused_cross_entropy_backward(H, M, K, D, metric):
 
 
 @pytest.mark.parametrize("H,M,K,D", [(1, 128, 32, 256), (1, 1000, 1000, 256), (2, 333, 1030, 200), (1, 4097, 64, 132),
-                                     (3, 129, 7, 256), (1, 70000, 96, 256)])
+                                     (3, 129, 7, 256), (1, 70000, 96, 256),
+                                     # Dp = 512: four roles per row block (S1, S2, G1, G2), 64 rows per workgroup
+                                     (1, 128, 64, 512), (2, 333, 1030, 400), (1, 4097, 96, 300), (1, 65, 33, 512), (1, 20000, 260, 512)])
 @pytest.mark.parametrize("metric", [0, 1])
 def test_cross_entropy_backward_wave_pair_kernel_equals_one_wave_kernel(H, M, K, D, metric):
-    """Dp = 256: the wave-pair kernel (S sweep and G sweep on two waves, weights handed over through LDS) runs the same chains
-    as the one-wave kernel (VQ_CE_NO_ROLES=1) -- equal bits, at ragged row counts, codebook tails and zero distances."""
+    """Dp = 256 / 512: the role-split kernels (S sweep and G sweep on different waves, accumulators and weights handed over
+    through LDS) run the same chains as the one-wave kernel (VQ_CE_NO_ROLES=1) -- equal bits, at ragged row counts, codebook
+    tails and zero distances."""
     import os
     native = _native()
     x, cb = make_x((H, M, D), "S"), make_codebook(H, K, D, "S")

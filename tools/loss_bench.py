@@ -51,6 +51,33 @@ def main():
         os.environ.pop("VQ_CE_NO_ROLES", None)
         print(f"CE backward ({'one-wave kernel' if env else 'wave-pair roles'})  {t:8.3f} ms  {2 * flops / t / 1e9:7.1f} TFLOP/s "
               f"({2 * flops / t / 1e9 / 157.3:.3f} of peak)")
+    # the same kernels on a long sweep (K = 8192): the per-block costs amortised
+    M8, K8 = 65536, 8192
+    x8 = x[:, :M8].contiguous()
+    cb8 = torch.randn((1, K8, D), device=dev, generator=g)
+    tgt8 = torch.randint(0, K8, (1, M8), device=dev, generator=g)
+    pk8 = native.pack_codebooks(cb8, 0)
+    lse8, tl8 = native.softmax_stats(x8, cb8, target=tgt8, packed=pk8)
+    f8 = 4.0 * M8 * K8 * D
+    t = timed(lambda: native.ce_backward(x8, cb8, lse8, tl8, tgt8, coef, packed=pk8), n=5, warm=2)
+    print(f"CE backward D=256 K=8192 M=65536 (wave-pair roles)  {t:8.3f} ms  {f8 / t / 1e9:7.1f} TFLOP/s ({f8 / t / 1e9 / 157.3:.3f} of peak)")
+    t = timed(lambda: native.softmax_stats(x8, cb8, target=tgt8, packed=pk8), n=5, warm=2)
+    print(f"softmax stats D=256 K=8192 M=65536  {t:8.3f} ms  {f8 / 2 / t / 1e9:7.1f} TFLOP/s ({f8 / 2 / t / 1e9 / 157.3:.3f} of peak)")
+    # D = 512 (cfg3b's per-head shape): four roles per row block against the one-wave kernel (two workgroups per row block)
+    M5, K5, D5 = 65536, 8192, 512
+    x5 = torch.randn((1, M5, D5), device=dev, generator=g)
+    cb5 = torch.randn((1, K5, D5), device=dev, generator=g)
+    tgt5 = torch.randint(0, K5, (1, M5), device=dev, generator=g)
+    pk5 = native.pack_codebooks(cb5, 0)
+    lse5, tl5 = native.softmax_stats(x5, cb5, target=tgt5, packed=pk5)
+    f5 = 4.0 * M5 * K5 * D5
+    for env in ("", "1"):
+        if env:
+            os.environ["VQ_CE_NO_ROLES"] = env
+        t = timed(lambda: native.ce_backward(x5, cb5, lse5, tl5, tgt5, coef, packed=pk5), n=5, warm=2)
+        os.environ.pop("VQ_CE_NO_ROLES", None)
+        print(f"CE backward D=512 K=8192 M=65536 ({'one-wave kernel' if env else 'four roles'})  {t:8.3f} ms  {f5 / t / 1e9:7.1f} TFLOP/s "
+              f"({f5 / t / 1e9 / 157.3:.3f} of peak, algorithmic 4MKD)")
     out = torch.empty((1, 65536, K), device=dev)
     t = timed(lambda: native.similarities(x[:, :65536], cb, packed=packed, out=out))
     print(f"similarities, 65536-row chunk   {t:8.3f} ms  {flops / 4 / t / 1e9:7.1f} TFLOP/s  {out.numel() * 4 / t / 1e6:7.1f} GB/s written")

@@ -325,8 +325,28 @@ int launch_ce_bwd_roles_t(const CeBwdParams &p, int H, hipStream_t s) {
     return 0;
 }
 
+// Dp = 512: four roles per row block (S cut in two, G in two halves of the positions), 64 rows per workgroup
+template <int METRIC>
+int launch_ce_bwd_roles512_t(const CeBwdParams &p, int H, hipStream_t s) {
+    const size_t lds = (size_t)CeRoles512Geo::LDS_F * 4;
+    auto kern = vq_ce_backward_roles512<METRIC>;
+    static thread_local bool attr_done[kMaxDevices] = {};
+    if (int rc = allow_big_lds(kern, attr_done)) return rc;
+    dim3 grid((unsigned)((p.M + 32 * CeRoles512Geo::NQ - 1) / (32 * CeRoles512Geo::NQ)), (unsigned)H, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "vq_ce_backward_roles512 launch");
+    return 0;
+}
+
 template <int DP>
 int launch_ce_bwd_m(const CeBwdParams &p, int H, int metric, hipStream_t s) {
+    if constexpr (DP == 512) {
+        if (getenv("VQ_CE_NO_ROLES") == nullptr) {
+            if (metric == VQ_METRIC_EUCLID) return launch_ce_bwd_roles512_t<VQ_METRIC_EUCLID>(p, H, s);
+            return launch_ce_bwd_roles512_t<VQ_METRIC_DOT>(p, H, s);
+        }
+    }
     if constexpr (DP == 256) {
         if (getenv("VQ_CE_NO_ROLES") == nullptr) {  // (read per call: tests switch between the two kernels in one process)
             if (metric == VQ_METRIC_EUCLID) return launch_ce_bwd_roles_t<VQ_METRIC_EUCLID>(p, H, s);
