@@ -99,18 +99,21 @@ def test_key_planes_need_no_init_and_no_atomics(H, M, K, D, metric):
     assert torch.equal(fin2["idx"], fin1["idx"]) and torch.equal(fin2["out"], fin1["out"])
 
 
-@pytest.mark.parametrize("M,K,D,Q", [(70000, 1024, 256, 4), (80000, 256, 256, 3), (140000, 512, 200, 2), (65536, 1024, 256, 3)])
+@pytest.mark.parametrize("M,K,D,Q,H", [(70000, 1024, 256, 4, 1), (80000, 256, 256, 3, 1), (140000, 512, 200, 2, 1), (65536, 1024, 256, 3, 1),
+                                       (66000, 2048, 256, 3, 1), (36000, 1024, 128, 3, 2), (34000, 1024, 400, 2, 1), (35001, 4096, 64, 2, 2)])
 @pytest.mark.parametrize("training", [False, True])
-def test_residual_stacks_with_awkward_row_counts(M, K, D, Q, training):
-    """Residual stacks cannot split K; a row count just above a multiple of 256 x CUs runs on 128-row (4-wave) workgroups so
-    that the remainder costs half a round.  Whatever the workgroup size: equal to the stages searched one by one with the
-    one-thread-per-row kernel and the reference's residual arithmetic (residual_vq.py:232-233, vector_quantize_pytorch.py:273)."""
+def test_residual_stacks_with_awkward_row_counts(M, K, D, Q, H, training):
+    """Residual stacks cannot split K inside one launch; a row count just above a multiple of 256 x CUs runs its whole rounds on the
+    fused kernel and the remainder STAGE BY STAGE (K split over all CUs, the finalize writing the next residual), or -- short
+    sweeps -- on 128-row workgroups.  Whatever the plan: equal to the stages searched one by one with the one-thread-per-row
+    kernel and the reference's residual arithmetic (residual_vq.py:232-233, vector_quantize_pytorch.py:273)."""
     from vector_quantization import native
 
     native.load()
     g = torch.Generator(device=DEV).manual_seed(M + K + Q)
-    x = torch.randn((1, M, D), device=DEV, generator=g)
-    cbs = torch.stack([torch.randn((K, D), device=DEV, generator=g) * 2.0 ** (-i / 2.0) for i in range(Q)])[None].contiguous()
+    x = torch.randn((H, M, D), device=DEV, generator=g)
+    cbs = torch.stack([torch.stack([torch.randn((K, D), device=DEV, generator=g) * 2.0 ** (-i / 2.0) for i in range(Q)])
+                       for _ in range(H)]).contiguous()
     r = native.quantize(x, cbs, ste=training, want_sq_err=training, want_best=True)
     res, out = x, torch.zeros_like(x)
     for q in range(Q):

@@ -590,6 +590,9 @@ int check_common(const vq_args *a) {
 // count: a few planes) -- when the planes do not fit, the splits fall back to ONE plane combined with atomic MIN
 constexpr long long kKeyPlanesExtraBytes = 8ll << 20;
 long long ws_keys_bytes(int H, long long M) { return ((long long)H * M * 8 + 255) / 256 * 256 + kKeyPlanesExtraBytes; }
+// residual stacks of many rows: room at the END of the workspace for the residual rows of a tail run stage by stage (plan_residual_tail)
+constexpr long long kResidualTailBytes = 64ll << 20;
+inline long long residual_tail_room(int H, long long M, int Q) { return (Q > 1 && (long long)H * M > 32768) ? kResidualTailBytes : 0; }  // (more than one round of 128-row workgroups)
 // loss partials: one float per wave, stage and 32 rows (16 rows for the wave-pair kernel of 256 < D <= 512)
 long long ws_loss_floats(int H, long long M, int Q) { return (long long)H * ((M + 15) / 16 + 16) * Q + (long long)H * 8192 + 64; }
 
@@ -618,9 +621,21 @@ void fill_search_params(SearchParams &p, const vq_args *a) {
                  (!a->cb || (a->cb_hs % 4 == 0 && a->cb_qs % 4 == 0 && aligned16(a->cb)))) ? 1 : 0;
 }
 
-int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipStream_t s, int *nparts_out, int key_planes = 1) {
+// one stage of a residual stack run stage by stage (residual_tail_staged): where the next residual goes, whether `out` accumulates
+struct ResidualStage {
+    float *res_next;
+    int out_acc;
+};
+
+int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipStream_t s, int *nparts_out, int key_planes = 1,
+                 const ResidualStage *rst = nullptr) {
     FinalizeParams f;
     memset(&f, 0, sizeof(f));
+    if (rst) {
+        f.residual = 1;
+        f.res_next = rst->res_next;
+        f.out_acc = rst->out_acc;
+    }
     f.keys = keys;
     f.nparts = key_planes;
     f.part_stride = (long long)a->H * a->M;
@@ -632,7 +647,8 @@ int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipS
     f.loss_part = loss_part;
     f.M = a->M; f.D = a->D; f.metric = a->metric; f.ste = (a->flags & VQ_F_STE) ? 1 : 0;
     f.vec = (a->D % 4 == 0 && a->cb_hs % 4 == 0 && aligned16(a->cb) && (!a->out || (a->out_rs % 4 == 0 && a->out_hs % 4 == 0 && aligned16(a->out))) &&
-             (!(f.ste || loss_part) || (a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x)))) ? 1 : 0;
+             (!(f.ste || loss_part || f.res_next) || (a->x_rs % 4 == 0 && a->x_hs % 4 == 0 && aligned16(a->x))) &&
+             (!f.res_next || aligned16(f.res_next))) ? 1 : 0;
     long long blocks = (a->M + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
@@ -971,7 +987,8 @@ int64_t vq_workspace_bytes_wide(int H, int64_t M, int K, int D) {
 
 int64_t vq_workspace_bytes(int H, int64_t M, int Q) {
     if (H <= 0 || M < 0 || Q <= 0) return 0;
-    return ws_keys_bytes(H, M) + ws_loss_floats(H, M, Q) * 4 + 256;
+    // (+ residual stacks of many rows: room for the residual rows of a tail run stage by stage, see plan_residual_tail)
+    return ws_keys_bytes(H, M) + ws_loss_floats(H, M, Q) * 4 + 256 + residual_tail_room(H, M, Q);
 }
 
 int vq_pack_codebooks_f32(const float *cb, int n_codebooks, int64_t cb_stride, int K, int D, int metric, float *packed,
@@ -1083,6 +1100,95 @@ int vq_finalize_key_planes_f32(const vq_args *a, const int64_t *keys, int n_plan
 
 constexpr uint32_t kFlagAccumulateSqErr = 0x80000000u;  // never set by callers: vq_quantize_f32 masks it off
 
+// A single stage as  search into key planes (K split over workgroups: every split stores its winners into a plane of its own, no
+// init launch, no atomics; one plane + atomic MIN if the planes do not fit the workspace)  +  finalize (MIN over the planes,
+// gather, straight-through, squared error).  `rst`: the stage belongs to a residual stack run stage by stage.
+static int split_stage(const vq_args *a, int planned_splits, int acc, void *stream, const ResidualStage *rst) {
+    hipStream_t s = (hipStream_t)stream;
+    long long *keys = (long long *)a->workspace;
+    float *loss_part = (float *)((char *)a->workspace + ws_keys_bytes(a->H, a->M));
+    const KeysPlan kp = plan_keys(a, planned_splits);
+    int planes = 1;
+    if (kp.mfma && (long long)kp.splits * a->H * a->M * 8 <= ws_keys_bytes(a->H, a->M)) planes = kp.splits;
+    int rc;
+    if (!kp.mfma || planes != kp.splits) {
+        rc = vq_keys_init((int64_t *)keys, (int64_t)a->H * a->M, stream);
+        if (rc) return rc;
+        planes = 1;
+    }
+    rc = run_search_keys(a, 0, keys, s, planned_splits, kp.mfma && planes == kp.splits ? (long long)a->H * a->M : 0);
+    if (rc) return rc;
+    int nparts = 0;
+    rc = run_finalize(a, keys, a->sq_err ? loss_part : nullptr, s, &nparts, planes, rst);
+    if (rc) return rc;
+    if (a->sq_err) {
+        hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_part, (long long)nparts, 1, a->sq_err, acc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
+    }
+    return 0;
+}
+
+// ---- residual stacks whose row count leaves the last round of workgroups mostly empty -------------------------------------
+// A residual launch cannot split K (every stage needs the whole codebook per row), so M = 70 000 at cfg4's shape pays half a
+// round of 128-row workgroups for 7 % of a round of work.  The rows that fill whole rounds run on the fused kernel; the
+// remainder runs STAGE BY STAGE, each stage a K-split search over all CUs + a finalize that also writes the next residual
+// (r - quant, the fused kernel's arithmetic) into the workspace and accumulates `out`: 2-3 short launches per stage instead of
+// half a round of sweep per stage.  Returns the rows (per head) of the fused part, 0 = keep the single fused launch.
+
+static long long plan_residual_tail(const vq_args *a, int DP, int cus) {
+    if (a->Q < 2 || DP == 0 || (a->flags & (VQ_F_SQERR_PER_HEAD | VQ_F_FORCE_SIMPLE | VQ_F_FORCE_SPLIT))) return 0;
+    if (residual_tail_room(a->H, a->M, a->Q) == 0) return 0;  // (the workspace has no room for the tail's residual rows)
+    static const bool off = getenv("VQ_NO_RESIDUAL_TAIL") != nullptr;
+    if (off) return 0;
+    const int rpw = fused_rows_per_wg(DP);  // 256 (128 at Dp = 512)
+    const long long nblk_h = (a->M + rpw - 1) / rpw;
+    long long full = nblk_h * a->H / cus;
+    while (full > 0 && (full * cus) % a->H) --full;  // whole rounds that are whole row blocks of every head
+    const long long rem = nblk_h * a->H - full * cus;  // workgroups of the last, partly filled round
+    if (full < 1 || rem == 0) return 0;
+    const long long m1 = full * cus / a->H * rpw, mt = a->M - m1;
+    if (mt <= 0 || (long long)a->H * mt * a->D * 4 > kResidualTailBytes) return 0;
+    const int nsub = (a->K + kTileCodes - 1) / kTileCodes;
+    const double sweep_us = nsub * sub_tile_us(DP);  // one stage of one round
+    // the fused alternative: a whole round, or ~0.55 of one when 128-row workgroups fit one per CU (Dp = 256, see quantize_impl)
+    const double fused_rounds = (DP == 256 && 2 * rem <= cus) ? 0.55 : 1.0;
+    const double fused_us = fused_rounds * a->Q * sweep_us;
+    // staged: per stage ~20 us of launches + finalize, the tail's share of a round of sweep (K split: ~1.4 x for the extra prologues)
+    const double staged_us = a->Q * (20.0 + 1.4 * sweep_us * (double)rem / cus);
+    return staged_us < 0.8 * fused_us ? m1 : 0;
+}
+
+static int residual_tail_staged(const vq_args *a, long long m1, void *stream) {
+    const long long mt = a->M - m1;
+    float *R = (float *)((char *)a->workspace + a->workspace_bytes - kResidualTailBytes);  // [H][mt][D]
+    for (int q = 0; q < a->Q; ++q) {
+        vq_args t = *a;
+        t.M = mt;
+        t.Q = 1;
+        if (q == 0) {
+            t.x = a->x + m1 * a->x_rs;
+        } else {
+            t.x = R;
+            t.x_rs = a->D;
+            t.x_hs = mt * a->D;
+        }
+        t.cb = a->cb + (long long)q * a->cb_qs;
+        t.packed = a->packed + (long long)q * a->pk_qs;
+        if (a->out) t.out = a->out + m1 * a->out_rs;
+        t.idx = a->idx + m1 * a->idx_rs + (long long)q * a->idx_qs;
+        if (a->best) t.best = a->best + m1 * a->idx_rs + (long long)q * a->idx_qs;
+        if (a->sq_err) t.sq_err = a->sq_err + q;
+        t.workspace_bytes = a->workspace_bytes - kResidualTailBytes;
+        ResidualStage rst;
+        rst.res_next = (q + 1 < a->Q) ? R : nullptr;
+        rst.out_acc = q > 0;
+        const int rc = split_stage(&t, 0, /*acc=*/1, stream, &rst);  // (the fused part wrote sq_err[q]; this adds the tail's sum)
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     int rc = check_common(a);
     if (rc) return rc;
@@ -1125,6 +1231,17 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
             rc = quantize_impl(&a1, stream, nullptr);
             if (rc) return rc;
             return quantize_impl(&a2, stream, nullptr);
+        }
+    }
+
+    if (!simple && a->Q > 1 && !acc && a->packed && a->workspace_bytes >= vq_workspace_bytes(a->H, a->M, a->Q)) {
+        const long long m1 = plan_residual_tail(a, DP, cus);
+        if (m1 > 0 && m1 < a->M) {  // whole rounds on the fused kernel, the remainder stage by stage (K split over all CUs)
+            vq_args a1 = *a;
+            a1.M = m1;
+            rc = quantize_impl(&a1, stream, nullptr);
+            if (rc) return rc;
+            return residual_tail_staged(a, m1, stream);
         }
     }
 
@@ -1204,28 +1321,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
     if (a->Q != 1) return fail(VQ_E_UNSUPPORTED, "vq_quantize: residual stages need the MFMA kernel (D <= 512)");
     if ((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err)
         return fail(VQ_E_UNSUPPORTED, "vq_quantize: per-head squared errors need the MFMA kernel (D <= 512)");
-    // K split over workgroups: every split stores its winners into a key plane of its own and the finalize takes the MIN
-    // over the planes (no init launch, no atomics); if the planes do not fit the workspace, one plane + atomic MIN
-    const int sp = fused ? 0 : planned_splits;
-    const KeysPlan kp = plan_keys(a, sp);
-    int planes = 1;
-    if (kp.mfma && (long long)kp.splits * a->H * a->M * 8 <= ws_keys_bytes(a->H, a->M)) planes = kp.splits;
-    if (!kp.mfma || planes != kp.splits) {
-        rc = vq_keys_init((int64_t *)keys, (int64_t)a->H * a->M, stream);
-        if (rc) return rc;
-        planes = 1;
-    }
-    rc = run_search_keys(a, 0, keys, s, sp, kp.mfma && planes == kp.splits ? (long long)a->H * a->M : 0);
-    if (rc) return rc;
-    int nparts = 0;
-    rc = run_finalize(a, keys, a->sq_err ? loss_part : nullptr, s, &nparts, planes);
-    if (rc) return rc;
-    if (a->sq_err) {
-        hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_part, (long long)nparts, 1, a->sq_err, acc);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
-    }
-    return 0;
+    return split_stage(a, fused ? 0 : planned_splits, acc, stream, nullptr);
 }
 
 int vq_quantize_f32(const vq_args *a, void *stream) {
