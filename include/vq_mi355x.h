@@ -93,7 +93,9 @@ typedef struct vq_args {
     int64_t workspace_bytes;
 } vq_args;
 
-/* Bytes of scratch vq_quantize_f32 / vq_search_keys_f32 may need for (H, M, Q). */
+/* Bytes of scratch vq_quantize_f32 / vq_search_keys_f32 may need for (H, M, Q): packed keys (+ 8 MiB of key planes for K
+ * splits), squared-error partials and -- residual stacks (Q > 1) of more than 32 768 rows -- 64 MiB for the residual rows of a
+ * partly filled last round of workgroups, which is searched stage by stage (residual_vq.py:212-243 on the remainder). */
 int64_t vq_workspace_bytes(int H, int64_t M, int Q);
 
 /*
