@@ -41,3 +41,17 @@ def oracle():
 
     vq_oracle.build()
     return vq_oracle
+
+
+@pytest.fixture(params=["fused", "staged"])
+def residual_plan(request):
+    """Residual stacks of few rows (or with a partly filled last round of workgroups) run stage by stage with K split over all CUs;
+    VQ_NO_RESIDUAL_TAIL=1 keeps the one fused launch (residual in registers).  Kernel-level tests run under BOTH plans."""
+    import os
+
+    if request.param == "fused":
+        os.environ["VQ_NO_RESIDUAL_TAIL"] = "1"
+    else:
+        os.environ.pop("VQ_NO_RESIDUAL_TAIL", None)
+    yield request.param
+    os.environ.pop("VQ_NO_RESIDUAL_TAIL", None)

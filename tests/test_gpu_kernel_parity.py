@@ -82,7 +82,7 @@ def test_alternate_paths_bit_exact(oracle, flags_name, H, M, K, D, metric):
                                      (5, 200, 64, 128)])
 @pytest.mark.parametrize("training", [False, True])
 @pytest.mark.parametrize("cls", ["S", "G"])
-def test_residual_bit_exact(oracle, Q, M, K, D, training, cls):
+def test_residual_bit_exact(oracle, Q, M, K, D, training, cls, residual_plan):
     native = _native()
     x = make_x((M, D), cls)
     cbs = make_rvq_codebooks(Q, K, D, cls)

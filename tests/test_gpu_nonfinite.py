@@ -156,7 +156,7 @@ def test_poisoned_two_byte_rows(oracle, dtype, M, K, D):
 @pytest.mark.parametrize("D,K,Q", [(64, 128, 3), (256, 256, 4), (100, 70, 2), (512, 64, 2)])
 @pytest.mark.parametrize("ste", [False, True])
 @pytest.mark.parametrize("poison", ["rows", "codes"])
-def test_poisoned_residual_stack(oracle, D, K, Q, ste, poison):
+def test_poisoned_residual_stack(oracle, D, K, Q, ste, poison, residual_plan):
     """One fused launch for all stages: a repaired winner must also feed the residual of the following stages."""
     from gen import make_rvq_codebooks
 

@@ -115,7 +115,7 @@ RESIDUAL_CASES = [
 
 @pytest.mark.parametrize("H,Q,M,K,D,metric", RESIDUAL_CASES)
 @pytest.mark.parametrize("training", [False, True])
-def test_residual_stacks_on_the_pair_kernel(oracle, H, Q, M, K, D, metric, training):
+def test_residual_stacks_on_the_pair_kernel(oracle, H, Q, M, K, D, metric, training, residual_plan):
     """256 < D <= 512, Q > 1 (round 3): both waves of a pair update their half of the residual after every sweep.  Bit-exact
     against the CPU oracle's residual loop (residual_vq.py:212-243) and equal to the one-wave kernel (VQ_PAIR_NO_MULTI=1)."""
     import os
@@ -146,7 +146,7 @@ def test_residual_stacks_on_the_pair_kernel(oracle, H, Q, M, K, D, metric, train
 
 @pytest.mark.parametrize("training", [False, True])
 @pytest.mark.parametrize("poison_codes", [False, True])
-def test_residual_stacks_on_the_pair_kernel_non_finite(oracle, training, poison_codes):
+def test_residual_stacks_on_the_pair_kernel_non_finite(oracle, training, poison_codes, residual_plan):
     """Rows holding NaN / inf (and a NaN inside a later stage's codebook): wave A dumps its half of the flagged rows, wave B
     repairs them by the plain rule (ATen's argmax: the first NaN wins) -- equal to the oracle's residual loop."""
     native = _native()

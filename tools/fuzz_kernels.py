@@ -4,7 +4,7 @@
 Single stage: random (H, M, K, D, metric, ste) -> the launcher's choice (one-block, persistent, wave-pair, split-K, main + tail)
 must equal the scalar kernel bit for bit (indices, winning values, outputs) -- both follow the oracle's k-ordered chain.
 Rows wider than 512 dims (sliced sweep, chains carried through the workspace): the same check, D up to 2100.
-Residual stacks: random (Q, M, K, D, train) against the CPU oracle (indices and outputs exact).
+Residual stacks: random (Q, M, K, D, train) against the CPU oracle (indices and outputs exact), as one fused launch or stage by stage.
 One configuration in five is poisoned with NaN / +-inf entries in rows and / or codes (ATen's argmax rule: the first NaN wins)."""
 import os
 import sys
@@ -97,12 +97,20 @@ def run(budget: float = 60.0, seed: int = 0, verbose: bool = True):
                     _poison(rng, cbs, 1)
             with np.errstate(invalid="ignore", over="ignore"):
                 ref = vq_oracle.rvq_forward(x.numpy(), cbs.numpy(), 0, training=train)
-            r = native.quantize(x[None].to(dev), cbs[None].contiguous().to(dev), ste=train, want_sq_err=train)
-            torch.cuda.synchronize()
+            # few rows: the launcher would run the stack stage by stage (K split per stage); half of the configurations keep the
+            # one fused launch (residual in registers) instead
+            fused_plan = bool(rng.integers(0, 2))
+            if fused_plan:
+                os.environ["VQ_NO_RESIDUAL_TAIL"] = "1"
+            try:
+                r = native.quantize(x[None].to(dev), cbs[None].contiguous().to(dev), ste=train, want_sq_err=train)
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("VQ_NO_RESIDUAL_TAIL", None)
             ok = (np.array_equal(r["idx"][0].cpu().numpy(), ref["idx"]) and _same(r["out"][0].cpu(), torch.from_numpy(ref["out"]))
                   and _same(r["best"][0].cpu(), torch.from_numpy(ref["best"])))
             if not ok:
-                raise AssertionError(f"MISMATCH residual: Q={Q} M={M} K={K} D={D} train={train} poisoned={poisoned}")
+                raise AssertionError(f"MISMATCH residual: Q={Q} M={M} K={K} D={D} train={train} poisoned={poisoned} fused_plan={fused_plan}")
             n2 += 1
         n4 += int(poisoned)
         if verbose and (n1 + n2) % 20 == 0:

@@ -592,9 +592,16 @@ constexpr long long kKeyPlanesExtraBytes = 8ll << 20;
 long long ws_keys_bytes(int H, long long M) { return ((long long)H * M * 8 + 255) / 256 * 256 + kKeyPlanesExtraBytes; }
 // residual stacks of many rows: room at the END of the workspace for the residual rows of a tail run stage by stage (plan_residual_tail)
 constexpr long long kResidualTailBytes = 64ll << 20;
-inline long long residual_tail_room(int H, long long M, int Q) { return (Q > 1 && (long long)H * M > 32768) ? kResidualTailBytes : 0; }  // (more than one round of 128-row workgroups)
+inline long long residual_tail_room(int H, long long M, int Q) {  // (the row width is not known here: 512 dims, capped)
+    if (Q < 2) return 0;
+    const long long all = ((long long)H * M * 512 * 4 + 255) / 256 * 256;
+    return all < kResidualTailBytes ? all : kResidualTailBytes;
+}
 // loss partials: one float per wave, stage and 32 rows (16 rows for the wave-pair kernel of 256 < D <= 512)
 long long ws_loss_floats(int H, long long M, int Q) { return (long long)H * ((M + 15) / 16 + 16) * Q + (long long)H * 8192 + 64; }
+
+// keys + loss partials of a call, rounded to 256 bytes: what lies in front of the residual rows of a stack's staged tail
+long long ws_core_bytes(int H, long long M, int Q) { return (ws_keys_bytes(H, M) + ws_loss_floats(H, M, Q) * 4 + 256 + 255) / 256 * 256; }
 
 void fill_search_params(SearchParams &p, const vq_args *a) {
     memset(&p, 0, sizeof(p));
@@ -988,7 +995,7 @@ int64_t vq_workspace_bytes_wide(int H, int64_t M, int K, int D) {
 int64_t vq_workspace_bytes(int H, int64_t M, int Q) {
     if (H <= 0 || M < 0 || Q <= 0) return 0;
     // (+ residual stacks of many rows: room for the residual rows of a tail run stage by stage, see plan_residual_tail)
-    return ws_keys_bytes(H, M) + ws_loss_floats(H, M, Q) * 4 + 256 + residual_tail_room(H, M, Q);
+    return ws_core_bytes(H, M, Q) + residual_tail_room(H, M, Q);
 }
 
 int vq_pack_codebooks_f32(const float *cb, int n_codebooks, int64_t cb_stride, int K, int D, int metric, float *packed,
@@ -1134,34 +1141,38 @@ static int split_stage(const vq_args *a, int planned_splits, int acc, void *stre
 // round of 128-row workgroups for 7 % of a round of work.  The rows that fill whole rounds run on the fused kernel; the
 // remainder runs STAGE BY STAGE, each stage a K-split search over all CUs + a finalize that also writes the next residual
 // (r - quant, the fused kernel's arithmetic) into the workspace and accumulates `out`: 2-3 short launches per stage instead of
-// half a round of sweep per stage.  Returns the rows (per head) of the fused part, 0 = keep the single fused launch.
+// half a round of sweep per stage.  The same holds for a stack of FEW rows (less than one round: M = 8192 occupies 32 CUs, or 64
+// at one wave per SIMD): then every row runs stage by stage.  Returns the rows (per head) of the fused part -- 0: all rows
+// staged -- or -1 = keep the single fused launch.
 
 static long long plan_residual_tail(const vq_args *a, int DP, int cus) {
-    if (a->Q < 2 || DP == 0 || (a->flags & (VQ_F_SQERR_PER_HEAD | VQ_F_FORCE_SIMPLE | VQ_F_FORCE_SPLIT))) return 0;
-    if (residual_tail_room(a->H, a->M, a->Q) == 0) return 0;  // (the workspace has no room for the tail's residual rows)
-    static const bool off = getenv("VQ_NO_RESIDUAL_TAIL") != nullptr;
-    if (off) return 0;
+    if (a->Q < 2 || DP == 0 || (a->flags & (VQ_F_SQERR_PER_HEAD | VQ_F_FORCE_SIMPLE | VQ_F_FORCE_SPLIT))) return -1;
+    if (getenv("VQ_NO_RESIDUAL_TAIL") != nullptr) return -1;  // (read per call: tests run both plans in one process)
     const int rpw = fused_rows_per_wg(DP);  // 256 (128 at Dp = 512)
     const long long nblk_h = (a->M + rpw - 1) / rpw;
     long long full = nblk_h * a->H / cus;
     while (full > 0 && (full * cus) % a->H) --full;  // whole rounds that are whole row blocks of every head
     const long long rem = nblk_h * a->H - full * cus;  // workgroups of the last, partly filled round
-    if (full < 1 || rem == 0) return 0;
+    if (rem == 0) return -1;
     const long long m1 = full * cus / a->H * rpw, mt = a->M - m1;
-    if (mt <= 0 || (long long)a->H * mt * a->D * 4 > kResidualTailBytes) return 0;
+    if (mt <= 0 || (long long)a->H * mt * a->D * 4 > residual_tail_room(a->H, a->M, a->Q)) return -1;  // (no room for the residual rows)
     const int nsub = (a->K + kTileCodes - 1) / kTileCodes;
+    if (nsub < 8) return -1;  // (too short to split)
     const double sweep_us = nsub * sub_tile_us(DP);  // one stage of one round
-    // the fused alternative: a whole round, or ~0.55 of one when 128-row workgroups fit one per CU (Dp = 256, see quantize_impl)
-    const double fused_rounds = (DP == 256 && 2 * rem <= cus) ? 0.55 : 1.0;
+    // the fused alternative: a whole round, or ~0.55 of one when 128-row workgroups fit one per CU (Dp <= 256: a lone 4-wave
+    // workgroup has the matrix pipe to itself, see quantize_impl)
+    const long long rem4 = ((mt + 127) / 128) * a->H;
+    const double fused_rounds = (DP <= 256 && rem4 <= cus) ? 0.55 : 1.0;
     const double fused_us = fused_rounds * a->Q * sweep_us;
     // staged: per stage ~20 us of launches + finalize, the tail's share of a round of sweep (K split: ~1.4 x for the extra prologues)
     const double staged_us = a->Q * (20.0 + 1.4 * sweep_us * (double)rem / cus);
-    return staged_us < 0.8 * fused_us ? m1 : 0;
+    return staged_us < 0.8 * fused_us ? m1 : -1;
 }
 
 static int residual_tail_staged(const vq_args *a, long long m1, void *stream) {
     const long long mt = a->M - m1;
-    float *R = (float *)((char *)a->workspace + a->workspace_bytes - kResidualTailBytes);  // [H][mt][D]
+    // [H][mt][D], behind the keys and the loss partials of the whole call
+    float *R = (float *)((char *)a->workspace + ws_core_bytes(a->H, a->M, a->Q));
     for (int q = 0; q < a->Q; ++q) {
         vq_args t = *a;
         t.M = mt;
@@ -1179,7 +1190,7 @@ static int residual_tail_staged(const vq_args *a, long long m1, void *stream) {
         t.idx = a->idx + m1 * a->idx_rs + (long long)q * a->idx_qs;
         if (a->best) t.best = a->best + m1 * a->idx_rs + (long long)q * a->idx_qs;
         if (a->sq_err) t.sq_err = a->sq_err + q;
-        t.workspace_bytes = a->workspace_bytes - kResidualTailBytes;
+        t.workspace_bytes = ws_core_bytes(a->H, a->M, a->Q);
         ResidualStage rst;
         rst.res_next = (q + 1 < a->Q) ? R : nullptr;
         rst.out_acc = q > 0;
@@ -1236,11 +1247,16 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
 
     if (!simple && a->Q > 1 && !acc && a->packed && a->workspace_bytes >= vq_workspace_bytes(a->H, a->M, a->Q)) {
         const long long m1 = plan_residual_tail(a, DP, cus);
-        if (m1 > 0 && m1 < a->M) {  // whole rounds on the fused kernel, the remainder stage by stage (K split over all CUs)
-            vq_args a1 = *a;
-            a1.M = m1;
-            rc = quantize_impl(&a1, stream, nullptr);
-            if (rc) return rc;
+        if (m1 >= 0 && m1 < a->M) {  // whole rounds on the fused kernel, the remainder stage by stage (K split over all CUs)
+            if (m1 > 0) {
+                vq_args a1 = *a;
+                a1.M = m1;
+                rc = quantize_impl(&a1, stream, nullptr);
+                if (rc) return rc;
+            } else if (a->sq_err) {  // (no fused part: the stages ADD their sums)
+                hipError_t e = hipMemsetAsync(a->sq_err, 0, sizeof(double) * a->Q, s);
+                if (e != hipSuccess) return hip_fail(e, "vq_quantize: clearing sq_err");
+            }
             return residual_tail_staged(a, m1, stream);
         }
     }
