@@ -5,7 +5,8 @@ Single stage: random (H, M, K, D, metric, ste) -> the launcher's choice (one-blo
 must equal the scalar kernel bit for bit (indices, winning values, outputs) -- both follow the oracle's k-ordered chain.
 Rows wider than 512 dims (sliced sweep, chains carried through the workspace): the same check, D up to 2100.
 Residual stacks: random (Q, M, K, D, train) against the CPU oracle (indices and outputs exact), as one fused launch or stage by stage.
-One configuration in five is poisoned with NaN / +-inf entries in rows and / or codes (ATen's argmax rule: the first NaN wins)."""
+One configuration in five is poisoned with NaN / +-inf entries in rows and / or codes (ATen's argmax rule: the first NaN wins).
+Fused cross-entropy backward (8 % of the configurations): the role-split kernels against the one-wave kernel, equal bits."""
 import os
 import sys
 import time
@@ -38,10 +39,38 @@ def run(budget: float = 60.0, seed: int = 0, verbose: bool = True):
     dev = torch.device("cuda:0")
     native.load()
     t_end = time.time() + budget
-    n1 = n2 = n3 = n4 = 0
+    n1 = n2 = n3 = n4 = n5 = 0
     while time.time() < t_end:
         pick = rng.random()
         poisoned = rng.random() < 0.2
+        if pick >= 0.92:
+            # fused cross-entropy backward: the role-split kernels (Dp = 256 / 512) against the one-wave kernel, equal bits
+            D = int(rng.choice([130, 200, 256, 257, 300, 400, 512]))
+            K = int(rng.choice([1, 7, 33, 100, 256, 1000, 1030, 2048]))
+            H = int(rng.choice([1, 1, 2]))
+            M = int(rng.integers(1, 9000))
+            metric = int(rng.integers(0, 2))
+            g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+            x = torch.randn((H, M, D), generator=g) * (0.25 if metric else 1.0)
+            cb = torch.randn((H, K, D), generator=g)
+            tgt = torch.randint(0, K, (H, M), generator=g)
+            tgt[:, ::5] = -1
+            if metric == 0 and M > 3:
+                x[0, 3] = cb[0, K // 2]  # a zero distance
+            xs, cbs, ts = x.to(dev), cb.to(dev), tgt.to(dev)
+            lse, tl = native.softmax_stats(xs, cbs, metric=metric, target=ts)
+            coef = torch.tensor([0.5], device=dev)
+            a = native.ce_backward(xs, cbs, lse, tl, ts, coef, metric=metric)
+            os.environ["VQ_CE_NO_ROLES"] = "1"
+            try:
+                b = native.ce_backward(xs, cbs, lse, tl, ts, coef, metric=metric)
+            finally:
+                os.environ.pop("VQ_CE_NO_ROLES", None)
+            torch.cuda.synchronize()
+            if not torch.equal(a.view(torch.int32), b.view(torch.int32)):
+                raise AssertionError(f"MISMATCH ce_backward: H={H} M={M} K={K} D={D} metric={metric}")
+            n5 += 1
+            continue
         if pick < 0.7:
             wide = pick < 0.2
             if wide:
@@ -117,8 +146,8 @@ def run(budget: float = 60.0, seed: int = 0, verbose: bool = True):
             print(f"{n1} single-stage ({n3} of them wider than 512 dims), {n2} residual configurations agree ({n4} poisoned)", flush=True)
     if verbose:
         print(f"done: {n1} single-stage ({n3} wider than 512 dims) and {n2} residual random configurations "
-              f"({n4} with non-finite entries), all bit-exact", flush=True)
-    return dict(single=n1, wide=n3, residual=n2, poisoned=n4)
+              f"({n4} with non-finite entries) + {n5} cross-entropy backward configurations, all bit-exact", flush=True)
+    return dict(single=n1, wide=n3, residual=n2, poisoned=n4, ce_backward=n5)
 
 
 if __name__ == "__main__":
