@@ -33,14 +33,28 @@ def test_persistent_kernel_equals_one_block_kernel(oracle, H, M, K, D, metric):
     g = torch.Generator().manual_seed(M + K)
     x = torch.randn((H, M, D), generator=g).to(DEV)
     cb = torch.randn((H, 1, K, D), generator=g).to(DEV)
+    import os
     a = native.quantize(x, cb, metric=metric)                               # persistent kernel
-    b = native.quantize(x, cb, metric=metric, want_sq_err=True)             # one block per workgroup (loss partials wanted)
+    t = native.quantize(x, cb, metric=metric, ste=True, want_sq_err=True)   # persistent kernel, training-mode copy (round 3)
+    l = native.quantize(x, cb, metric=metric, want_sq_err=True)             # ... squared error only
+    os.environ["VQ_NO_PERSIST_TRAIN"] = "1"
+    try:
+        b = native.quantize(x, cb, metric=metric, want_sq_err=True)             # one block per workgroup
+        bt = native.quantize(x, cb, metric=metric, ste=True, want_sq_err=True)  # ... straight-through + squared error
+    finally:
+        os.environ.pop("VQ_NO_PERSIST_TRAIN", None)
     s = native.quantize(x, cb, metric=metric, flags=native.F_FORCE_SIMPLE)  # scalar kernel
     torch.cuda.synchronize()
-    for other in (b, s):
+    for other in (b, s, l):
         assert torch.equal(a["idx"], other["idx"])
         assert torch.equal(a["best"].view(torch.int32), other["best"].view(torch.int32))
         assert torch.equal(a["out"], other["out"])
+    assert torch.equal(t["idx"], bt["idx"]) and torch.equal(t["out"], bt["out"])  # x + (c - x): the same bits on both kernels
+    assert torch.equal(t["best"].view(torch.int32), bt["best"].view(torch.int32))
+    torch.testing.assert_close(t["sq_err"], bt["sq_err"], rtol=1e-6, atol=0)
+    torch.testing.assert_close(l["sq_err"], b["sq_err"], rtol=1e-6, atol=0)
+    want_err = (cb[:, 0][torch.arange(H, device=DEV)[:, None], a["idx"][..., 0]] - x).double().pow(2).sum()
+    torch.testing.assert_close(t["sq_err"].sum(), want_err, rtol=1e-6, atol=0)
     hh = torch.arange(H, device=DEV)[:, None]
     assert torch.equal(a["out"], cb[:, 0][hh, a["idx"][..., 0]])
     rows = torch.cat([torch.randperm(M, generator=torch.Generator().manual_seed(2))[:300], torch.arange(M - 50, M)])
@@ -62,7 +76,7 @@ def test_persistent_kernel_on_strided_head_views(oracle):
     with torch.no_grad():
         q, idx, _ = mod(x)
         mod.train()
-        q2, idx2, _ = mod(x, freeze_codebook=True)   # training forward: straight-through + loss -> one-block kernel
+        q2, idx2, _ = mod(x, freeze_codebook=True)   # training forward: straight-through + loss (the persistent kernel's TRAIN variant)
     assert torch.equal(idx, idx2)
     torch.testing.assert_close(q, q2, rtol=0, atol=1e-6)  # x + (c - x) vs c
     cbs = mod._codebook.embeddings
@@ -71,7 +85,7 @@ def test_persistent_kernel_on_strided_head_views(oracle):
 
 
 def test_the_persistent_kernel_is_the_one_that_runs():
-    """Guards the launcher's selection: the headline shape (cfg2) must go through vq_search_persist, a training call must not."""
+    """Guards the launcher's selection: the headline shape (cfg2) must go through vq_search_persist, eval and training call alike."""
     from torch.profiler import ProfilerActivity, profile
 
     native = _native()
@@ -91,5 +105,12 @@ def test_the_persistent_kernel_is_the_one_that_runs():
     if not plain:
         pytest.skip("torch.profiler reported no device activity on this build")
     assert any("vq_search_persist" in n for n in plain), plain
-    train = names(ste=True, want_sq_err=True)
-    assert not any("vq_search_persist" in n for n in train) and any("vq_search_mfma" in n for n in train), train
+    train = names(ste=True, want_sq_err=True)  # round 3: the training-mode call runs the persistent kernel's TRAIN variant
+    assert any("vq_search_persist" in n for n in train), train
+    import os
+    os.environ["VQ_NO_PERSIST_TRAIN"] = "1"
+    try:
+        train1 = names(ste=True, want_sq_err=True)
+    finally:
+        os.environ.pop("VQ_NO_PERSIST_TRAIN", None)
+    assert not any("vq_search_persist" in n for n in train1) and any("vq_search_mfma" in n for n in train1), train1

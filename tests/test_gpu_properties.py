@@ -308,7 +308,7 @@ def test_ema_accumulate_residual_matches_chain(H, M, K, D, Q, share):
             res = res - quant
 
 
-@pytest.mark.parametrize("kind", ["vq", "rvq"])
+@pytest.mark.parametrize("kind", ["vq", "rvq", "rvq_staged"])
 def test_graphed_forward_replays_on_new_data_and_new_weights(oracle, kind):
     """GraphedForward: one hipGraph launch per forward; new inputs and in-place codebook updates need no re-capture."""
     import vector_quantization as vq
@@ -317,8 +317,10 @@ def test_graphed_forward_replays_on_new_data_and_new_weights(oracle, kind):
     torch.manual_seed(0)
     if kind == "vq":
         mod = vq.VectorQuantize(dim=64, codebook_params=CodebookParams(dim=64, codebook_size=256)).to(DEV).eval()
-    else:
+    elif kind == "rvq":
         mod = vq.ResidualVQ(dim=64, num_quantizers=3, codebook_params=CodebookParams(dim=64, codebook_size=128)).to(DEV).eval()
+    else:  # few rows, long sweeps: the launcher runs the stack stage by stage (K-split search + finalize per stage) -- all of it captured
+        mod = vq.ResidualVQ(dim=64, num_quantizers=3, codebook_params=CodebookParams(dim=64, codebook_size=4096)).to(DEV).eval()
     fast = vq.GraphedForward(mod, torch.randn(32, 256, 64, device=DEV))
     for step in range(3):
         if step == 2:  # new weights, same buffers

@@ -221,17 +221,22 @@ int launch_pair_any(const SearchParams &p, int H, int splits, int metric, hipStr
 }
 #endif
 
-template <int METRIC>
+// workgroups per head of the persistent kernel: one 8-wave workgroup per CU, the CUs shared by the heads
+inline long long persist_grid_x(long long M, int H, int cus) {
+    const long long nblk = (M + 255) / 256;
+    long long gx = cus / H;
+    if (gx < 1) gx = 1;
+    return gx > nblk ? nblk : gx;
+}
+
+template <int METRIC, bool TRAIN = false>
 int launch_persist_t(const SearchParams &p, int H, int cus, hipStream_t s) {
     using G = Geo<256, 8>;
     const size_t lds = (size_t)G::MAIN_FLOATS_S * 4 + 2 * 8 * 32 * 4;
-    auto kern = vq_search_persist<256, 8, METRIC>;
+    auto kern = vq_search_persist<256, 8, METRIC, TRAIN>;
     static thread_local bool attr_done[kMaxDevices] = {};
     if (int rc = allow_big_lds(kern, attr_done)) return rc;
-    const long long nblk = (p.M + 255) / 256;
-    long long gx = cus / H;  // one 8-wave workgroup per CU (219 VGPRs): resident workgroups = CUs, shared by the heads
-    if (gx < 1) gx = 1;
-    if (gx > nblk) gx = nblk;
+    const long long gx = persist_grid_x(p.M, H, cus);
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)H, 1), dim3(512), lds, s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "vq_search_persist launch");
@@ -439,6 +444,8 @@ VQ_DEFINE_RESIDENT_PART(128)
 #if VQ_OWN(3)
 VQ_DEFINE_SEARCH_PART(256, 4)
 int part_persist(const SearchParams &p, int H, int cus, int metric, hipStream_t s) {
+    if (p.ste || p.loss_part)  // training-mode call: the deferred copy does the straight-through / squared-error arithmetic
+        return metric == VQ_METRIC_EUCLID ? launch_persist_t<VQ_METRIC_EUCLID, true>(p, H, cus, s) : launch_persist_t<VQ_METRIC_DOT, true>(p, H, cus, s);
     return metric == VQ_METRIC_EUCLID ? launch_persist_t<VQ_METRIC_EUCLID>(p, H, cus, s) : launch_persist_t<VQ_METRIC_DOT>(p, H, cus, s);
 }
 #endif
@@ -499,7 +506,9 @@ namespace {
 bool persist_selected(int DP, int waves, const SearchParams &p, int H, int splits, int cus) {
     static const bool off = getenv("VQ_NO_PERSIST") != nullptr;
     if (off || DP != 256 || waves != 8 || splits != 1 || p.Q != 1 || p.mode != kModeFused) return false;
-    if (p.ste || p.loss_part || p.lse || p.xt || !p.vec_x || !p.vec_fin || !p.out || p.D % 4) return false;
+    if (p.lse || p.xt || !p.vec_x || !p.vec_fin || p.D % 4) return false;
+    if (!p.out && !p.loss_part) return false;  // (nothing to copy)
+    if ((p.ste || p.loss_part) && getenv("VQ_NO_PERSIST_TRAIN") != nullptr) return false;  // (A/B and tests: training-mode calls on the one-block kernel; read per call)
     const int nsub = p.ntiles * sub_tiles(DP);
     if (nsub < 32 || nsub > 96) return false;  // one row per sub-tile needs 32; beyond ~100 the finalize is < 1 % of a block
     const long long nblk = (p.M + 32 * waves - 1) / (32 * waves);
@@ -1322,8 +1331,9 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
         if (rc) return rc;
         if (a->sq_err) {
             const bool pair = pair_selected(DP, a->Q, p.tiles_per_split);  // 8 waves (4 pairs) per 128 rows, one partial per wave
+            const bool pers = !res_img && persist_selected(DP, waves, p, a->H, 1, cus);  // one partial per wave of the resident workgroups
             const long long rows_per_wg = pair ? 128 : 32ll * waves;
-            const long long per_head = ((a->M + rows_per_wg - 1) / rows_per_wg) * (pair ? 8 : waves);
+            const long long per_head = pers ? persist_grid_x(a->M, a->H, cus) * 8 : ((a->M + rows_per_wg - 1) / rows_per_wg) * (pair ? 8 : waves);
             const bool by_head = (a->flags & VQ_F_SQERR_PER_HEAD) != 0;
             hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(a->Q, by_head ? a->H : 1), dim3(256), 0, s, loss_part,
                                by_head ? per_head : per_head * a->H, a->Q, a->sq_err, acc);
