@@ -128,3 +128,27 @@ def test_residual_stacks_with_awkward_row_counts(M, K, D, Q, H, training):
         res = res - quant
         out = out + quant
     assert torch.equal(r["out"], out)
+
+
+@pytest.mark.parametrize("M,K,D,Q,H", [(3000, 2048, 64, 3, 3), (36000, 1024, 128, 2, 2), (70000, 1024, 256, 2, 1)])
+def test_residual_stacks_per_head_squared_errors_under_both_plans(M, K, D, Q, H, residual_plan):
+    """GroupedResidualVQ's per-group losses (VQ_F_SQERR_PER_HEAD, sq_err [H][Q]): the stage-by-stage plan adds each stage's
+    per-head sums where the fused launch writes them -- same indices and outputs, sums equal to 1e-6."""
+    from vector_quantization import native
+
+    native.load()
+    g = torch.Generator(device=DEV).manual_seed(M + K + Q + H)
+    x = torch.randn((H, M, D), device=DEV, generator=g)
+    cbs = torch.stack([torch.stack([torch.randn((K, D), device=DEV, generator=g) * 2.0 ** (-i / 2.0) for i in range(Q)])
+                       for _ in range(H)]).contiguous()
+    r = native.quantize(x, cbs, ste=True, want_sq_err=True, sq_err_per_head=True)
+    res = x
+    for q in range(Q):
+        hh = torch.arange(H, device=DEV)[:, None]
+        code = cbs[:, q][hh, r["idx"][..., q]]
+        err = (code - res).double().pow(2).sum(dim=(1, 2))
+        torch.testing.assert_close(r["sq_err"][:, q], err, rtol=1e-6, atol=0)
+        res = res - (res + (code - res))
+    s = native.quantize(x, cbs, ste=True, want_sq_err=True)
+    assert torch.equal(r["idx"], s["idx"]) and torch.equal(r["out"], s["out"])
+    torch.testing.assert_close(r["sq_err"].sum(0), s["sq_err"], rtol=1e-6, atol=0)

@@ -668,7 +668,8 @@ int run_finalize(const vq_args *a, const long long *keys, float *loss_part, hipS
     long long blocks = (a->M + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)blocks, (unsigned)a->H), dim3(256), 0, s, f);
+    if (rst) hipLaunchKernelGGL(vq_finalize_kernel<true>, dim3((unsigned)blocks, (unsigned)a->H), dim3(256), 0, s, f);
+    else hipLaunchKernelGGL(vq_finalize_kernel<false>, dim3((unsigned)blocks, (unsigned)a->H), dim3(256), 0, s, f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "vq_finalize launch");
     if (nparts_out) *nparts_out = (int)(blocks * 4 * a->H);
@@ -1119,7 +1120,8 @@ constexpr uint32_t kFlagAccumulateSqErr = 0x80000000u;  // never set by callers:
 // A single stage as  search into key planes (K split over workgroups: every split stores its winners into a plane of its own, no
 // init launch, no atomics; one plane + atomic MIN if the planes do not fit the workspace)  +  finalize (MIN over the planes,
 // gather, straight-through, squared error).  `rst`: the stage belongs to a residual stack run stage by stage.
-static int split_stage(const vq_args *a, int planned_splits, int acc, void *stream, const ResidualStage *rst) {
+// `sq_err_hs` > 0: one squared-error sum per head, the heads `sq_err_hs` doubles apart (a stage of a grouped stack).
+static int split_stage(const vq_args *a, int planned_splits, int acc, void *stream, const ResidualStage *rst, int sq_err_hs = 0) {
     hipStream_t s = (hipStream_t)stream;
     long long *keys = (long long *)a->workspace;
     float *loss_part = (float *)((char *)a->workspace + ws_keys_bytes(a->H, a->M));
@@ -1138,7 +1140,10 @@ static int split_stage(const vq_args *a, int planned_splits, int acc, void *stre
     rc = run_finalize(a, keys, a->sq_err ? loss_part : nullptr, s, &nparts, planes, rst);
     if (rc) return rc;
     if (a->sq_err) {
-        hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_part, (long long)nparts, 1, a->sq_err, acc);
+        if (sq_err_hs > 0)  // the finalize's partials are [head][nparts / H]
+            hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1, a->H), dim3(256), 0, s, loss_part, (long long)(nparts / a->H), 1, a->sq_err, acc, sq_err_hs);
+        else
+            hipLaunchKernelGGL(vq_loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_part, (long long)nparts, 1, a->sq_err, acc);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "vq_loss_reduce launch");
     }
@@ -1155,7 +1160,7 @@ static int split_stage(const vq_args *a, int planned_splits, int acc, void *stre
 // staged -- or -1 = keep the single fused launch.
 
 static long long plan_residual_tail(const vq_args *a, int DP, int cus) {
-    if (a->Q < 2 || DP == 0 || (a->flags & (VQ_F_SQERR_PER_HEAD | VQ_F_FORCE_SIMPLE | VQ_F_FORCE_SPLIT))) return -1;
+    if (a->Q < 2 || DP == 0 || (a->flags & (VQ_F_FORCE_SIMPLE | VQ_F_FORCE_SPLIT))) return -1;
     if (getenv("VQ_NO_RESIDUAL_TAIL") != nullptr) return -1;  // (read per call: tests run both plans in one process)
     const int rpw = fused_rows_per_wg(DP);  // 256 (128 at Dp = 512)
     const long long nblk_h = (a->M + rpw - 1) / rpw;
@@ -1203,7 +1208,9 @@ static int residual_tail_staged(const vq_args *a, long long m1, void *stream) {
         ResidualStage rst;
         rst.res_next = (q + 1 < a->Q) ? R : nullptr;
         rst.out_acc = q > 0;
-        const int rc = split_stage(&t, 0, /*acc=*/1, stream, &rst);  // (the fused part wrote sq_err[q]; this adds the tail's sum)
+        t.flags &= ~VQ_F_SQERR_PER_HEAD;
+        const int by_head_hs = ((a->flags & VQ_F_SQERR_PER_HEAD) && a->sq_err) ? a->Q : 0;  // sq_err is [H][Q]: stage q of head h at h * Q + q
+        const int rc = split_stage(&t, 0, /*acc=*/1, stream, &rst, by_head_hs);  // (the fused part wrote sq_err[q]; this adds the tail's sum)
         if (rc) return rc;
     }
     return 0;
@@ -1263,7 +1270,7 @@ static int quantize_impl(const vq_args *a, void *stream, float *lse) {
                 rc = quantize_impl(&a1, stream, nullptr);
                 if (rc) return rc;
             } else if (a->sq_err) {  // (no fused part: the stages ADD their sums)
-                hipError_t e = hipMemsetAsync(a->sq_err, 0, sizeof(double) * a->Q, s);
+                hipError_t e = hipMemsetAsync(a->sq_err, 0, sizeof(double) * a->Q * ((a->flags & VQ_F_SQERR_PER_HEAD) ? a->H : 1), s);
                 if (e != hipSuccess) return hip_fail(e, "vq_quantize: clearing sq_err");
             }
             return residual_tail_staged(a, m1, stream);
