@@ -58,6 +58,17 @@ WORKLOADS = {
                        "K=8192, batch [64,1024,512] per GPU, eval; value = whole module forward, roofline = search kernel only"),
     "cfg4": dict(kind="rvq", dim=256, K=1024, Q=8, x_shape=(64, 1024, 256),
                  desc="ResidualVQ num_quantizers=8 codebook_size=1024 dim=256, batch [64,1024,256] per GPU, eval"),
+    # cfg4's stack at row counts that are NOT a multiple of a round of workgroups (not BASELINE configs; round 3's launch plans):
+    "cfg4_m70000": dict(kind="rvq", dim=256, K=1024, Q=8, x_shape=(70, 1000, 256),
+                        kernel_label="vq_search_mfma<.., MULTI> on the rows that fill whole rounds + the remaining 4464 rows stage by stage "
+                                     "(K-split search + finalize per stage); roofline = the whole launch sequence of one call",
+                        desc="ResidualVQ num_quantizers=8 codebook_size=1024 dim=256, batch [70,1000,256] per GPU (70 000 rows: 1.07 rounds "
+                             "of 256-row workgroups), eval"),
+    "cfg4_m8192": dict(kind="rvq", dim=256, K=1024, Q=8, x_shape=(8, 1024, 256),
+                       kernel_label="every stage a K-split search over all CUs + finalize (few rows: no fused part); roofline = the whole "
+                                    "launch sequence of one call",
+                       desc="ResidualVQ num_quantizers=8 codebook_size=1024 dim=256, batch [8,1024,256] per GPU (8192 rows: 32 row blocks "
+                            "on 256 CUs), eval"),
     "cfg1": dict(kind="vq", dim=64, K=256, x_shape=(32, 256, 64), desc="VectorQuantize dim=64 codebook_size=256, batch [32,256,64], eval"),
     # not a BASELINE config: rows wider than the 512 dims one launch holds (the reference has no width limit); the search is a
     # sequence of launches here (256-dim slices, chains carried through the workspace, then the finalize), timed as one
@@ -65,7 +76,7 @@ WORKLOADS = {
                      desc="VectorQuantize dim=1024 codebook_size=1024, batch [64,1024,1024] per GPU, eval (rows wider than 512 dims: "
                           "sliced sweep; roofline = the whole launch sequence of one search)"),
 }
-DEFAULT_LEGS = "k8192,cfg3a,cfg3b,cfg4,wide1024"
+DEFAULT_LEGS = "k8192,cfg3a,cfg3b,cfg4,wide1024,cfg4_m70000,cfg4_m8192"
 
 
 def log(*a):
@@ -316,7 +327,8 @@ def run_workload(name, args, device, rank, world, want_parity):
                 frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic_record(name),
                 traffic_source="profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this workload's bench command "
                                "(tools/profile_round.sh), per search; a recorded measurement, not taken during this run",
-                kernel=("vq_search_pair512<.., WIDE> x 512-dim slices (the last one finishes the call)" if head_dim(w) > 512 else
+                kernel=(w["kernel_label"] if "kernel_label" in w else
+                        "vq_search_pair512<.., WIDE> x 512-dim slices (the last one finishes the call)" if head_dim(w) > 512 else
                         "vq_search_pair512" if (head_dim(w) > 256 and w.get("Q", 1) == 1) else
                         "vq_search_persist" if (128 < head_dim(w) <= 256 and w.get("Q", 1) == 1 and 1024 <= w["K"] <= 3072) else
                         "vq_search_mfma"),
