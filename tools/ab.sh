@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B on the GPU box: bash tools/ab.sh "<quick_bench cases>" lib1.so lib2.so ...   (libs relative to vector-quantization-by-ml_amd/lib)
-mkdir -p gpurun_out/r2
+mkdir -p gpurun_out/r3
 cases=$1; shift
 for rep in 1 2; do
 for lib in "$@"; do
